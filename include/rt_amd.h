@@ -1,0 +1,182 @@
+/*
+ * rt_amd.h -- C ABI of librt_amd.so, the MI355X (gfx950) implementation of the
+ * per-pixel Monte Carlo path-tracing loop of sergeyrid/raytracing.
+ *
+ * The reference has no plugin / FFI interface: its only seams are the process command
+ * line (main.cpp:1244-1259) and three C++ functions called from main():
+ *
+ *     InputData  parseGLTF(string&, uint32_t w, uint32_t h)      main.cpp:866
+ *     SceneFloat generateScene(const InputData&)                 main.cpp:1235
+ *     void       printImage(SceneFloat&, string&)                main.cpp:856
+ *
+ * plus the inner seam  Intersection intersectScene(o, d, const InputData&)  main.cpp:1113.
+ * Each entry point below names the reference function it stands in for.  Plain C types
+ * only; every call returns RT_OK (0) or a negative code and never throws; the message of
+ * the last failure on the calling thread is available from rt_last_error().
+ *
+ * Ownership: the caller owns every buffer it passes for the duration of the call.  A
+ * rt_scene owns its device memory until rt_scene_destroy.  Output buffers are caller
+ * allocated.  Entry points ending in _dev take DEVICE pointers valid on the scene's GPU
+ * and a HIP stream (hipStream_t passed as void*, NULL = default stream); they enqueue
+ * work and return without synchronising.  The others take HOST pointers and return when
+ * the result is in place.
+ *
+ * Threading: calls on one rt_scene must not overlap (the scene holds scratch buffers and
+ * counters that every launch reuses).  Different scenes may be used from different threads.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_ERR_INVALID (-1)  /* bad argument / unsupported scene file content */
+#define RT_ERR_IO (-2)       /* file could not be read or written */
+#define RT_ERR_HIP (-3)      /* a HIP runtime call failed */
+#define RT_ERR_LIMIT (-4)    /* a size exceeds what the kernels were built for */
+
+/* Material types, values of main.cpp:55-59 (enum class Material). */
+#define RT_MAT_DIFFUSER 0
+#define RT_MAT_METALLIC 1
+#define RT_MAT_DIELECTRIC 2
+
+/* RNG modes of rt_render*.
+ * RT_RNG_REFERENCE reproduces main.cpp:1221-1225: one minstd_rand per pixel seeded with
+ * py*W+px, carried across that pixel's samples (so spp_begin must be 0).
+ * RT_RNG_COUNTER seeds a fresh minstd_rand per (pixel, sample) from a hash of
+ * (pixel, sample, seed); any sample range can then be rendered on any GPU. */
+#define RT_RNG_REFERENCE 0
+#define RT_RNG_COUNTER 1
+
+/* Pipelines of rt_render*: both produce the same estimator.
+ * RT_PIPE_MEGAKERNEL: one persistent thread per pixel, a lane starts its next sample as soon
+ * as its path ends.  RT_PIPE_WAVEFRONT: queue-per-bounce kernels (generate / trace / shade)
+ * over SoA ray and hit buffers with wave-level compaction; needs RT_RNG_COUNTER. */
+#define RT_PIPE_MEGAKERNEL 0
+#define RT_PIPE_WAVEFRONT 1
+
+#define RT_MISS_ID 0xFFFFFFFFu /* prim_id of a ray that hits nothing */
+#define RT_INF 10000.0f        /* t of a ray that hits nothing (INF, main.cpp:23) */
+
+/* InputData's camera fields, main.cpp:696-700. */
+typedef struct rt_camera {
+    float position[3];
+    float right[3];
+    float up[3];
+    float forward[3];
+    float tan_x; /* cameraFovTan.x = tan_y * W / H, main.cpp:1104 */
+    float tan_y; /* tan(yfov / 2), main.cpp:1013 */
+} rt_camera;
+
+/* MaterialData, main.cpp:61-66. */
+typedef struct rt_material {
+    float color[3];
+    float emission[3];
+    int32_t type; /* RT_MAT_* */
+    float ior;    /* always 1.5 from the loader (main.cpp:65) */
+} rt_material;
+
+/* The flattened InputData (main.cpp:689-706) handed across the boundary: a triangle soup in
+ * loader emission order (that order defines the primitive ids returned by the trace calls),
+ * one material index per triangle, the material table and the camera.  The light list
+ * (main.cpp:1096-1098) and the BVH are derived by rt_scene_create. */
+typedef struct rt_scene_desc {
+    const float *tri_verts;       /* ntri * 9 floats: A.xyz, B.xyz, C.xyz, world space */
+    const uint32_t *tri_material; /* ntri */
+    uint32_t ntri;
+    const rt_material *materials;
+    uint32_t nmat;
+    rt_camera camera;
+} rt_scene_desc;
+
+typedef struct rt_scene rt_scene;           /* device-resident scene */
+typedef struct rt_host_scene rt_host_scene; /* parsed scene file, host memory only */
+
+typedef struct rt_scene_stats {
+    uint32_t ntri;
+    uint32_t nlights;
+    uint32_t nnodes;      /* 64-byte two-child nodes */
+    uint32_t tree_height; /* edges on the longest root-to-leaf path */
+    double build_seconds; /* host BVH build + flatten */
+    uint64_t device_bytes;
+} rt_scene_stats;
+
+/* Counters accumulated on the device by the launches since the last rt_counters_reset:
+ * segments = rays traced (primary + every continuation; the light-pdf triangle tests of
+ * main.cpp:771-783 are not rays); nodes / tri_tests are only counted by the *_counted
+ * launches (rt_set_counting). */
+typedef struct rt_counters {
+    uint64_t segments;
+    uint64_t nodes;
+    uint64_t tri_tests;
+    uint64_t light_tests;
+} rt_counters;
+
+const char *rt_last_error(void);
+int rt_device_count(void);
+
+/* ---- scene files: stands in for parseGLTF, main.cpp:866-1111 (host only, no GPU call) ---- */
+int rt_gltf_load(const char *path, uint32_t width, uint32_t height, rt_host_scene **out);
+int rt_host_scene_get_desc(const rt_host_scene *hs, rt_scene_desc *out); /* pointers stay owned by hs */
+void rt_host_scene_free(rt_host_scene *hs);
+
+/* ---- scene upload: Triangle::update (main.cpp:527-536), the light list (1096-1098) and the
+ * acceleration structure (BVH::build, main.cpp:552-558 / 608-686, here a binned-SAH builder
+ * flattened to 64-byte nodes) ---- */
+int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out);
+void rt_scene_destroy(rt_scene *s);
+int rt_scene_get_stats(const rt_scene *s, rt_scene_stats *out);
+/* Copies of the flattened structure for checkers: nodes (nnodes * 16 floats), triangles in
+ * leaf order (ntri * 16 floats).  Either pointer may be NULL. */
+int rt_scene_get_flat(const rt_scene *s, float *nodes, float *tris);
+
+/* ---- closest hit: stands in for intersectScene / BVH::intersect, main.cpp:1113, 560-605 ---- */
+/* n rays, origins and directions as n*3 floats; prim_id[i] = loader-order triangle id or
+ * RT_MISS_ID, t[i] = hit distance or RT_INF. */
+int rt_intersect_rays(rt_scene *s, uint64_t n, const float *origins, const float *directions,
+                      uint32_t *prim_id, float *t);
+int rt_intersect_rays_dev(rt_scene *s, uint64_t n, const float *d_origins, const float *d_directions,
+                          uint32_t *d_prim_id, float *d_t, void *stream);
+/* The primary ray of sample 0 of every pixel (generateSample, main.cpp:1212-1216, with the
+ * engine seeded as in generatePixel, main.cpp:1221), row-major W*H outputs. */
+int rt_trace_primary(rt_scene *s, uint32_t width, uint32_t height, uint32_t *prim_id, float *t);
+int rt_trace_primary_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t *d_prim_id, float *d_t,
+                         void *stream);
+
+/* ---- render: stands in for generateScene / generatePixel's sample loop, main.cpp:1220-1242 ----
+ * radiance_sum[3*(py*W+px) + c] receives the SUM over samples [spp_begin, spp_begin+spp_count)
+ * of generateSample (linear radiance, before the mean / tonemap), so that partial sums of
+ * disjoint sample ranges from several GPUs add up to the full frame.  max_depth is
+ * InputData::rayDepth (6 in the reference, main.cpp:692). */
+int rt_render(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_begin, uint32_t spp_count,
+              uint32_t max_depth, int rng_mode, uint32_t seed, int pipeline, float *radiance_sum);
+int rt_render_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_begin, uint32_t spp_count,
+                  uint32_t max_depth, int rng_mode, uint32_t seed, int pipeline, float *d_radiance_sum,
+                  void *stream);
+
+/* ---- image: mean, ACES, gamma (main.cpp:1226-1231, 827-838), truncating byte conversion
+ * (colorFloatToInt, main.cpp:840-846), PPM writer (printImage, main.cpp:856-864) ---- */
+/* out_float (npixels*3, may be NULL) = SceneFloat contents; out_rgb (npixels*3, may be NULL). */
+int rt_tonemap(rt_scene *s, const float *radiance_sum, uint64_t npixels, uint32_t spp, float *out_float,
+               uint8_t *out_rgb);
+int rt_tonemap_dev(rt_scene *s, const float *d_radiance_sum, uint64_t npixels, uint32_t spp,
+                   float *d_out_float, uint8_t *d_out_rgb, void *stream);
+int rt_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb);
+
+/* ---- counters ---- */
+int rt_set_counting(rt_scene *s, int enable); /* 1: launches also count nodes / triangle tests (slower) */
+int rt_counters_reset(rt_scene *s, void *stream);
+int rt_counters_read(rt_scene *s, rt_counters *out); /* synchronises the device */
+
+/* The seed of the per-(pixel, sample) stream of RT_RNG_COUNTER (host helper for checkers). */
+uint32_t rt_counter_seed(uint32_t pixel, uint32_t sample, uint32_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

@@ -1,0 +1,237 @@
+"""Host-side mirror of the reference's three seams, on top of the C ABI:
+
+    parse_gltf(path, width, height)  ~ InputData parseGLTF(string&, w, h)      main.cpp:866
+    generate_scene(input_data)       ~ SceneFloat generateScene(const InputData&)  main.cpp:1235
+    print_image(scene_float, path)   ~ void printImage(SceneFloat&, string&)   main.cpp:856
+
+plus `Scene`, the device-resident scene with the lower-level calls (closest hit, partial
+sample ranges for multi-GPU, tone mapping).  All compute runs in librt_amd.so on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (PIPE_MEGAKERNEL, PIPE_WAVEFRONT, RNG_COUNTER, RNG_REFERENCE, MISS_ID, INF, RtError, check)
+
+MATERIAL_DTYPE = np.dtype([("color", "<f4", 3), ("emission", "<f4", 3), ("type", "<i4"), ("ior", "<f4")])
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        return None
+    if isinstance(stream, int):
+        return C.c_void_p(stream)
+    return C.c_void_p(stream.cuda_stream)  # torch.cuda.Stream
+
+
+class HostScene:
+    """A parsed scene file on the host: triangle soup, materials, camera (InputData's host half)."""
+
+    def __init__(self, tri_verts, tri_material, materials, camera):
+        self.tri_verts = np.ascontiguousarray(tri_verts, dtype=np.float32).reshape(-1, 3, 3)
+        self.tri_material = np.ascontiguousarray(tri_material, dtype=np.uint32)
+        self.materials = np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE)
+        self.camera = {k: (np.asarray(v, dtype=np.float32) if k in ("position", "right", "up", "forward")
+                           else np.float32(v)) for k, v in camera.items()}
+
+    def as_dict(self):
+        return dict(tri_verts=self.tri_verts, tri_material=self.tri_material, materials=self.materials,
+                    camera=self.camera)
+
+    def _desc(self):
+        d = _lib.SceneDesc()
+        d.tri_verts = self.tri_verts.ctypes.data
+        d.tri_material = self.tri_material.ctypes.data
+        d.ntri = self.tri_material.shape[0]
+        d.materials = self.materials.ctypes.data
+        d.nmat = self.materials.shape[0]
+        for k in ("position", "right", "up", "forward"):
+            getattr(d.camera, k)[:] = [float(x) for x in self.camera[k]]
+        d.camera.tan_x = float(self.camera["tan_x"])
+        d.camera.tan_y = float(self.camera["tan_y"])
+        return d
+
+
+def load_gltf(path, width, height):
+    """The host part of parseGLTF (main.cpp:866-1104): no GPU involved."""
+    L = _lib.lib()
+    h = C.c_void_p()
+    check(L.rt_gltf_load(str(path).encode(), int(width), int(height), C.byref(h)))
+    try:
+        d = _lib.SceneDesc()
+        check(L.rt_host_scene_get_desc(h, C.byref(d)))
+        n, nm = d.ntri, d.nmat
+        tv = np.ctypeslib.as_array(C.cast(d.tri_verts, C.POINTER(C.c_float)), shape=(n * 9,)).copy() if n else \
+            np.zeros(0, np.float32)
+        tm = np.ctypeslib.as_array(C.cast(d.tri_material, C.POINTER(C.c_uint32)), shape=(n,)).copy() if n else \
+            np.zeros(0, np.uint32)
+        mats = np.zeros(nm, dtype=MATERIAL_DTYPE)
+        if nm:
+            C.memmove(mats.ctypes.data, d.materials, nm * MATERIAL_DTYPE.itemsize)
+        cam = dict(position=np.array(d.camera.position[:], np.float32), right=np.array(d.camera.right[:], np.float32),
+                   up=np.array(d.camera.up[:], np.float32), forward=np.array(d.camera.forward[:], np.float32),
+                   tan_x=np.float32(d.camera.tan_x), tan_y=np.float32(d.camera.tan_y))
+    finally:
+        L.rt_host_scene_free(h)
+    return HostScene(tv, tm, mats, cam)
+
+
+class Scene:
+    """Device-resident scene: BVH + triangles + materials + lights + camera on one GPU."""
+
+    def __init__(self, host_scene, device=0):
+        if isinstance(host_scene, dict):
+            host_scene = HostScene(**host_scene)
+        self.host = host_scene
+        self.device = int(device)
+        self._h = C.c_void_p()
+        d = host_scene._desc()
+        check(_lib.lib().rt_scene_create(C.byref(d), self.device, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().rt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- introspection -----------------------------------------------------------------------
+    def stats(self):
+        s = _lib.SceneStats()
+        check(_lib.lib().rt_scene_get_stats(self._h, C.byref(s)))
+        return dict(ntri=s.ntri, nlights=s.nlights, nnodes=s.nnodes, tree_height=s.tree_height,
+                    build_seconds=s.build_seconds, device_bytes=int(s.device_bytes))
+
+    def flat(self):
+        st = self.stats()
+        nodes = np.empty((st["nnodes"], 16), dtype=np.float32)
+        tris = np.empty((st["ntri"], 16), dtype=np.float32)
+        check(_lib.lib().rt_scene_get_flat(self._h, _p(nodes), _p(tris)))
+        return nodes, tris
+
+    def set_counting(self, enable):
+        check(_lib.lib().rt_set_counting(self._h, int(bool(enable))))
+
+    def reset_counters(self, stream=None):
+        check(_lib.lib().rt_counters_reset(self._h, _stream_ptr(stream)))
+
+    def counters(self):
+        c = _lib.Counters()
+        check(_lib.lib().rt_counters_read(self._h, C.byref(c)))
+        return dict(segments=int(c.segments), nodes=int(c.nodes), tri_tests=int(c.tri_tests),
+                    light_tests=int(c.light_tests))
+
+    # -- closest hit (intersectScene, main.cpp:1113) -----------------------------------------
+    def intersect(self, origins, directions):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        if o.shape != d.shape:
+            raise ValueError("origins and directions must have the same shape")
+        n = o.shape[0]
+        ids = np.empty(n, dtype=np.uint32)
+        t = np.empty(n, dtype=np.float32)
+        check(_lib.lib().rt_intersect_rays(self._h, n, _p(o), _p(d), _p(ids), _p(t)))
+        return ids, t
+
+    def trace_primary(self, width, height):
+        n = int(width) * int(height)
+        ids = np.empty(n, dtype=np.uint32)
+        t = np.empty(n, dtype=np.float32)
+        check(_lib.lib().rt_trace_primary(self._h, int(width), int(height), _p(ids), _p(t)))
+        return ids, t
+
+    def trace_primary_dev(self, width, height, prim_id_ptr, t_ptr, stream=None):
+        check(_lib.lib().rt_trace_primary_dev(self._h, int(width), int(height), C.c_void_p(prim_id_ptr),
+                                             C.c_void_p(t_ptr), _stream_ptr(stream)))
+
+    # -- render (generateScene, main.cpp:1235) -----------------------------------------------
+    def render(self, width, height, spp, max_depth=6, rng_mode=RNG_REFERENCE, seed=0, spp_begin=0,
+               pipeline=PIPE_MEGAKERNEL):
+        """Returns the per-pixel radiance SUM over the sample range, shape (H*W, 3) float32."""
+        out = np.empty((int(width) * int(height), 3), dtype=np.float32)
+        check(_lib.lib().rt_render(self._h, int(width), int(height), int(spp_begin), int(spp), int(max_depth),
+                                   int(rng_mode), int(seed), int(pipeline), _p(out)))
+        return out
+
+    def render_dev(self, width, height, spp, radiance_sum_ptr, max_depth=6, rng_mode=RNG_COUNTER, seed=0,
+                   spp_begin=0, pipeline=PIPE_MEGAKERNEL, stream=None):
+        """Enqueue a render into a device buffer of W*H*3 floats (e.g. tensor.data_ptr())."""
+        check(_lib.lib().rt_render_dev(self._h, int(width), int(height), int(spp_begin), int(spp), int(max_depth),
+                                       int(rng_mode), int(seed), int(pipeline), C.c_void_p(radiance_sum_ptr),
+                                       _stream_ptr(stream)))
+
+    # -- image (main.cpp:1226-1231, 840-846) -------------------------------------------------
+    def tonemap(self, radiance_sum, spp):
+        rs = np.ascontiguousarray(radiance_sum, dtype=np.float32).reshape(-1, 3)
+        f = np.empty_like(rs)
+        b = np.empty(rs.shape, dtype=np.uint8)
+        check(_lib.lib().rt_tonemap(self._h, _p(rs), rs.shape[0], int(spp), _p(f), _p(b)))
+        return f, b
+
+    def tonemap_dev(self, radiance_sum_ptr, npixels, spp, out_float_ptr=None, out_rgb_ptr=None, stream=None):
+        check(_lib.lib().rt_tonemap_dev(self._h, C.c_void_p(radiance_sum_ptr), int(npixels), int(spp),
+                                       C.c_void_p(out_float_ptr) if out_float_ptr else None,
+                                       C.c_void_p(out_rgb_ptr) if out_rgb_ptr else None, _stream_ptr(stream)))
+
+
+class InputData:
+    """What parseGLTF returns in the reference (main.cpp:689-706): image size, depth, sample
+    count and the scene, here resident on a GPU."""
+
+    def __init__(self, scene, width, height, samples=0, ray_depth=6):
+        self.scene = scene
+        self.width = int(width)
+        self.height = int(height)
+        self.ray_depth = int(ray_depth)  # const 6 in the reference (main.cpp:692)
+        self.samples = int(samples)
+
+
+class SceneFloat:
+    """main.cpp:44-53: the tone-mapped float image, row-major from the top-left."""
+
+    def __init__(self, width, height, data, rgb8):
+        self.width = width
+        self.height = height
+        self.data = data    # (H*W, 3) float32 in [0, 1]
+        self.rgb8 = rgb8    # (H*W, 3) uint8, truncating conversion
+
+
+def parse_gltf(path, width, height, device=0):
+    host = load_gltf(path, width, height)
+    return InputData(Scene(host, device=device), width, height)
+
+
+def generate_scene(input_data, rng_mode=RNG_REFERENCE, pipeline=PIPE_MEGAKERNEL, seed=0):
+    s = input_data.scene
+    rs = s.render(input_data.width, input_data.height, input_data.samples, max_depth=input_data.ray_depth,
+                  rng_mode=rng_mode, seed=seed, pipeline=pipeline)
+    f, b = s.tonemap(rs, input_data.samples)
+    return SceneFloat(input_data.width, input_data.height, f, b)
+
+
+def print_image(scene_float, path):
+    rgb = np.ascontiguousarray(scene_float.rgb8, dtype=np.uint8)
+    check(_lib.lib().rt_write_ppm(str(path).encode(), int(scene_float.width), int(scene_float.height), _p(rgb)))
+
+
+def counter_seed(pixel, sample, seed):
+    return int(_lib.lib().rt_counter_seed(int(pixel), int(sample), int(seed)))
+
+
+def device_count():
+    return int(_lib.lib().rt_device_count())

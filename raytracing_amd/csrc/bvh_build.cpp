@@ -1,0 +1,355 @@
+// bvh_build.cpp -- host acceleration-structure build and flattening into the HBM layout.
+//
+// Replaces BVH::build (main.cpp:552-558, 608-686).  The reference sweeps every split position
+// on three fully sorted axes per node, with sweep buffers sized by the whole scene (O(N^2)),
+// and uses 16-bit ids.  The closest hit does not depend on the tree's shape (apart from exact
+// distance ties), so this builder is free to differ: 32-bin SAH on triangle centroids,
+// O(N log N), subtrees built as OpenMP tasks, 32-bit ids, leaves of at most 4 triangles like
+// the reference (main.cpp:618), and a bounded height so that the kernels' fixed per-lane stack
+// can never overflow.  Per-triangle derived data follows Triangle::update (main.cpp:527-536).
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+#include <omp.h>
+
+#include "host_math.h"
+#include "rt_internal.h"
+
+namespace rt {
+namespace {
+
+const float EPS = 0.0001f;  // main.cpp:22
+constexpr int kBins = 32;
+constexpr uint32_t kTaskCutoff = 4096;  // ranges smaller than this are built inline
+constexpr uint32_t kBfsTop = 2047;      // nodes laid out breadth-first at the front of the array
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = 3.0e38f;
+            hi[k] = -3.0e38f;
+        }
+    }
+    void grow(const Box &b) {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], b.lo[k]);
+            hi[k] = std::max(hi[k], b.hi[k]);
+        }
+    }
+    void grow(const float *p) {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], p[k]);
+            hi[k] = std::max(hi[k], p[k]);
+        }
+    }
+    float half_area() const {
+        float a = hi[0] - lo[0], b = hi[1] - lo[1], c = hi[2] - lo[2];
+        if (a < 0.f || b < 0.f || c < 0.f) return 0.f;
+        return a * b + a * c + b * c;
+    }
+};
+
+struct Prim {
+    Box box;
+    float c[3];
+    uint32_t id;
+};
+
+struct BNode {
+    Box box[2];
+    int32_t child[2];  // >= 0: BNode index; < 0: ~((first << 3) | (count - 1))
+};
+
+inline int32_t leaf_ref(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
+
+// Inner levels a range of n triangles needs at least (leaves hold <= kMaxLeafTris).
+inline uint32_t min_levels(uint32_t n) {
+    uint32_t leaves = (n + kMaxLeafTris - 1) / kMaxLeafTris, lv = 0;
+    while ((1u << lv) < leaves) ++lv;
+    return lv;
+}
+
+struct Builder {
+    std::vector<Prim> prims;
+    std::vector<BNode> nodes;
+    std::atomic<uint32_t> next{0};
+
+    uint32_t alloc() { return next.fetch_add(1, std::memory_order_relaxed); }
+
+    Box bounds(uint32_t b, uint32_t e) const {
+        Box r;
+        r.reset();
+        for (uint32_t i = b; i < e; ++i) r.grow(prims[i].box);
+        return r;
+    }
+
+    // Splits [b, e) (more than kMaxLeafTris triangles) at inner level `level` (root = 1) and
+    // returns the split position.
+    uint32_t split(uint32_t b, uint32_t e, uint32_t level) {
+        const uint32_t n = e - b;
+        Box cb;
+        cb.reset();
+        for (uint32_t i = b; i < e; ++i) cb.grow(prims[i].c);
+
+        float bestCost = 3.0e38f;
+        int bestAxis = -1, bestBin = -1;
+        for (int axis = 0; axis < 3; ++axis) {
+            float ext = cb.hi[axis] - cb.lo[axis];
+            if (!(ext > 0.f)) continue;
+            Box bb[kBins];
+            uint32_t cnt[kBins];
+            for (int k = 0; k < kBins; ++k) {
+                bb[k].reset();
+                cnt[k] = 0;
+            }
+            const float scale = (float)kBins / ext;
+            for (uint32_t i = b; i < e; ++i) {
+                int k = (int)((prims[i].c[axis] - cb.lo[axis]) * scale);
+                k = std::min(std::max(k, 0), kBins - 1);
+                bb[k].grow(prims[i].box);
+                ++cnt[k];
+            }
+            float rightArea[kBins];
+            uint32_t rightCnt[kBins];
+            Box acc;
+            acc.reset();
+            uint32_t c = 0;
+            for (int k = kBins - 1; k > 0; --k) {
+                acc.grow(bb[k]);
+                c += cnt[k];
+                rightArea[k] = acc.half_area();
+                rightCnt[k] = c;
+            }
+            acc.reset();
+            c = 0;
+            for (int k = 0; k < kBins - 1; ++k) {
+                acc.grow(bb[k]);
+                c += cnt[k];
+                uint32_t nl = c, nr = rightCnt[k + 1];
+                if (nl == 0 || nr == 0) continue;
+                // both sides must still fit under the height bound
+                if (level + min_levels(nl) > kMaxTreeHeight || level + min_levels(nr) > kMaxTreeHeight) continue;
+                float cost = acc.half_area() * (float)nl + rightArea[k + 1] * (float)nr;
+                if (cost < bestCost) {
+                    bestCost = cost;
+                    bestAxis = axis;
+                    bestBin = k;
+                }
+            }
+        }
+
+        if (bestAxis >= 0) {
+            const float lo = cb.lo[bestAxis];
+            const float scale = (float)kBins / (cb.hi[bestAxis] - lo);
+            const int axis = bestAxis, bin = bestBin;
+            auto mid = std::partition(prims.begin() + b, prims.begin() + e, [=](const Prim &p) {
+                int k = (int)((p.c[axis] - lo) * scale);
+                k = std::min(std::max(k, 0), kBins - 1);
+                return k <= bin;
+            });
+            uint32_t m = (uint32_t)(mid - prims.begin());
+            if (m > b && m < e) return m;
+        }
+        // No usable SAH split (coincident centroids, or the height bound forbids every
+        // candidate): halve the range along the widest centroid axis.
+        int axis = 0;
+        for (int k = 1; k < 3; ++k)
+            if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
+        uint32_t m = b + n / 2;
+        std::nth_element(prims.begin() + b, prims.begin() + m, prims.begin() + e,
+                         [axis](const Prim &x, const Prim &y) { return x.c[axis] < y.c[axis]; });
+        return m;
+    }
+
+    int32_t build_child(uint32_t b, uint32_t e, uint32_t level) {
+        if (e - b <= kMaxLeafTris) return leaf_ref(b, e - b);
+        uint32_t id = alloc();
+        build_node(id, b, e, level);
+        return (int32_t)id;
+    }
+
+    void build_node(uint32_t id, uint32_t b, uint32_t e, uint32_t level) {
+        uint32_t m = split(b, e, level);
+        BNode &nd = nodes[id];
+        nd.box[0] = bounds(b, m);
+        nd.box[1] = bounds(m, e);
+        if (e - b >= kTaskCutoff) {
+            int32_t c0 = 0, c1 = 0;
+#pragma omp task shared(c0) firstprivate(b, m, level)
+            c0 = build_child(b, m, level + 1);
+#pragma omp task shared(c1) firstprivate(m, e, level)
+            c1 = build_child(m, e, level + 1);
+#pragma omp taskwait
+            nodes[id].child[0] = c0;
+            nodes[id].child[1] = c1;
+        } else {
+            int32_t c0 = build_child(b, m, level + 1);
+            int32_t c1 = build_child(m, e, level + 1);
+            nodes[id].child[0] = c0;
+            nodes[id].child[1] = c1;
+        }
+    }
+};
+
+// Conservative padding: the device slab test must never reject a box that contains a hit the
+// exact-arithmetic triangle test accepts, including zero-thickness boxes of axis-aligned walls.
+inline float pad_lo(float v) { return v - (1.0e-5f + std::fabs(v) * 4.0e-7f); }
+inline float pad_hi(float v) { return v + (1.0e-5f + std::fabs(v) * 4.0e-7f); }
+
+inline float bits_to_float(uint32_t u) {
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+uint32_t height_of(const std::vector<BNode> &nodes, int32_t ref) {
+    if (ref < 0) return 0;
+    return 1 + std::max(height_of(nodes, nodes[ref].child[0]), height_of(nodes, nodes[ref].child[1]));
+}
+
+}  // namespace
+
+void build_flat_scene(const rt_scene_desc &desc, FlatScene &out) {
+    auto t0 = std::chrono::steady_clock::now();
+    const uint32_t n = desc.ntri;
+    if (n >= kMaxTriangles) throw std::runtime_error("too many triangles (limit 2^28 - 1)");
+    if (n && (!desc.tri_verts || !desc.tri_material)) throw std::runtime_error("null triangle arrays");
+    if (desc.nmat && !desc.materials) throw std::runtime_error("null material table");
+    for (uint32_t i = 0; i < n; ++i)
+        if (desc.tri_material[i] >= desc.nmat) throw std::runtime_error("triangle names a missing material");
+    for (size_t i = 0; i < (size_t)n * 9; ++i)
+        if (!std::isfinite(desc.tri_verts[i])) throw std::runtime_error("non-finite vertex coordinate");
+
+    Builder B;
+    B.prims.resize(n);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        const float *v = desc.tri_verts + 9 * i;
+        Prim &p = B.prims[i];
+        p.box.reset();
+        p.box.grow(v);
+        p.box.grow(v + 3);
+        p.box.grow(v + 6);
+        for (int k = 0; k < 3; ++k) p.c[k] = 0.5f * (p.box.lo[k] + p.box.hi[k]);
+        p.id = (uint32_t)i;
+    }
+
+    // Node 0 is always an inner node, so the kernels never special-case tiny scenes.
+    B.nodes.resize(std::max<uint32_t>(n, 1));
+    uint32_t root = B.alloc();
+    Box never;
+    for (int k = 0; k < 3; ++k) never.lo[k] = never.hi[k] = 3.0e30f;  // a far-away point: always culled
+    if (n <= kMaxLeafTris) {
+        BNode &nd = B.nodes[root];
+        nd.box[0] = n ? B.bounds(0, n) : never;
+        nd.box[1] = never;
+        nd.child[0] = nd.child[1] = leaf_ref(0, 1);
+        if (n) nd.child[0] = leaf_ref(0, n);
+    } else {
+#pragma omp parallel
+#pragma omp single
+        B.build_node(root, 0, n, 1);
+    }
+    const uint32_t nnodes = B.next.load();
+    const uint32_t height = height_of(B.nodes, (int32_t)root);
+    if (height > kMaxTreeHeight) throw std::runtime_error("internal: BVH height bound violated");
+
+    // Layout: the top of the tree breadth-first (those nodes are the hot, shared ones and sit
+    // contiguously at the front), every subtree below it depth-first.
+    std::vector<uint32_t> order;  // new index -> old index
+    order.reserve(nnodes);
+    std::vector<uint32_t> newIndex(nnodes, 0);
+    {
+        std::vector<uint32_t> frontier{root}, nextFrontier;
+        while (!frontier.empty() && order.size() + frontier.size() <= kBfsTop) {
+            nextFrontier.clear();
+            for (uint32_t id : frontier) {
+                order.push_back(id);
+                for (int c = 0; c < 2; ++c)
+                    if (B.nodes[id].child[c] >= 0) nextFrontier.push_back((uint32_t)B.nodes[id].child[c]);
+            }
+            frontier.swap(nextFrontier);
+        }
+        std::vector<uint32_t> stack;
+        for (uint32_t sub : frontier) {
+            stack.push_back(sub);
+            while (!stack.empty()) {
+                uint32_t id = stack.back();
+                stack.pop_back();
+                order.push_back(id);
+                if (B.nodes[id].child[1] >= 0) stack.push_back((uint32_t)B.nodes[id].child[1]);
+                if (B.nodes[id].child[0] >= 0) stack.push_back((uint32_t)B.nodes[id].child[0]);
+            }
+        }
+    }
+    if (order.size() != nnodes) throw std::runtime_error("internal: BVH layout lost nodes");
+    for (uint32_t k = 0; k < nnodes; ++k) newIndex[order[k]] = k;
+
+    out.nnodes = nnodes;
+    out.ntri = n;
+    out.tree_height = height;
+    out.nodes.assign((size_t)nnodes * 16, 0.f);
+    for (uint32_t k = 0; k < nnodes; ++k) {
+        const BNode &nd = B.nodes[order[k]];
+        float *q = &out.nodes[(size_t)k * 16];
+        const Box &L = nd.box[0], &R = nd.box[1];
+        const bool lreal = L.lo[0] <= L.hi[0] && L.lo[0] < 1.0e30f;
+        const bool rreal = R.lo[0] <= R.hi[0] && R.lo[0] < 1.0e30f;
+        float l[6], r[6];
+        for (int a = 0; a < 3; ++a) {
+            l[a] = lreal ? pad_lo(L.lo[a]) : L.lo[a];
+            l[3 + a] = lreal ? pad_hi(L.hi[a]) : L.hi[a];
+            r[a] = rreal ? pad_lo(R.lo[a]) : R.lo[a];
+            r[3 + a] = rreal ? pad_hi(R.hi[a]) : R.hi[a];
+        }
+        q[0] = l[0]; q[1] = l[1]; q[2] = l[2]; q[3] = l[3];
+        q[4] = l[4]; q[5] = l[5]; q[6] = r[0]; q[7] = r[1];
+        q[8] = r[2]; q[9] = r[3]; q[10] = r[4]; q[11] = r[5];
+        int32_t c0 = nd.child[0] >= 0 ? (int32_t)newIndex[nd.child[0]] : nd.child[0];
+        int32_t c1 = nd.child[1] >= 0 ? (int32_t)newIndex[nd.child[1]] : nd.child[1];
+        q[12] = bits_to_float((uint32_t)c0);
+        q[13] = bits_to_float((uint32_t)c1);
+    }
+
+    // Triangles in leaf order, with the derived data of Triangle::update (main.cpp:527-536).
+    out.tris.assign((size_t)std::max<uint32_t>(n, 1) * 16, 0.f);
+    std::vector<uint32_t> posOfId(n);
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < (int64_t)n; ++k) {
+        const uint32_t id = B.prims[k].id;
+        posOfId[id] = (uint32_t)k;
+        const float *v = desc.tri_verts + 9 * (size_t)id;
+        hm::vec3 A = hm::V3(v[0], v[1], v[2]), Bv = hm::V3(v[3], v[4], v[5]), C = hm::V3(v[6], v[7], v[8]);
+        hm::vec3 AB = Bv - A, AC = C - A;
+        hm::vec3 N = hm::cross(AB, AC);
+        float pdfConst = 2.f / hm::length(N);
+        float *q = &out.tris[(size_t)k * 16];
+        q[0] = A.x; q[1] = A.y; q[2] = A.z; q[3] = AB.x;
+        q[4] = AB.y; q[5] = AB.z; q[6] = AC.x; q[7] = AC.y;
+        q[8] = AC.z; q[9] = N.x; q[10] = N.y; q[11] = N.z;
+        q[12] = bits_to_float(id);
+        q[13] = bits_to_float(desc.tri_material[id]);
+        q[14] = pdfConst;
+        q[15] = 0.f;
+    }
+    if (n == 0) {  // one never-hit dummy so leaf_ref(0, 1) stays in bounds
+        float *q = &out.tris[0];
+        q[0] = q[1] = q[2] = 3.0e30f;
+        q[12] = bits_to_float(RT_MISS_ID);
+    }
+
+    // Light list in loader order (main.cpp:1096-1098): length(emission) > EPS.
+    out.lights.clear();
+    for (uint32_t id = 0; id < n; ++id) {
+        const rt_material &m = desc.materials[desc.tri_material[id]];
+        if (hm::length(hm::V3(m.emission[0], m.emission[1], m.emission[2])) > EPS) out.lights.push_back(posOfId[id]);
+    }
+    out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // namespace rt

@@ -1,0 +1,328 @@
+// gltf_host.cpp -- host scene loading: .gltf JSON + external .bin buffers -> triangle soup,
+// material table and camera.  Stands in for parseGLTF (main.cpp:866-1111) up to, but not
+// including, the acceleration-structure build; it honours the reference loader's rules so the
+// same file yields the same triangles, materials and camera:
+//   * external buffers only, resolved against the scene file's directory (main.cpp:875-882)
+//   * every bufferView needs buffer / byteLength / byteOffset; byteStride is ignored (885-891)
+//   * material rules of main.cpp:894-927 (default METALLIC, metallicFactor < 1e-4 -> DIFFUSER,
+//     baseColorFactor alpha < 1 - 1e-4 -> DIELECTRIC, emission x emissive_strength)
+//   * POSITION is float32 VEC3 at stride 12 from view.byteOffset + accessor.byteOffset; indices
+//     are u16/u32 SCALAR read from view.byteOffset only (1038-1078)
+//   * node matrix = T*R*S or the column-major `matrix`; children are composed in one ascending
+//     pass; the camera takes its own local transform only (958-1026)
+//   * every node with a mesh is instantiated, `scenes` is ignored (1028-1031)
+// Unlike the reference (undefined behaviour on a missing key, no bounds checks), malformed
+// input is rejected with an error message.
+#include <chrono>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+#include "host_math.h"
+#include "json_min.hpp"
+#include "rt_internal.h"
+
+namespace {
+
+const float EPS = 0.0001f;  // main.cpp:22
+
+struct BufferView {
+    size_t buffer, byteLength, byteOffset;
+};
+struct Accessor {
+    size_t bufferView, count, componentType, byteOffset;
+    std::string type;
+};
+struct MeshPrimitive {
+    size_t position, indices, material;
+};
+
+std::string dir_of(const std::string &path) {
+    size_t k = path.find_last_of('/');
+    return k == std::string::npos ? std::string() : path.substr(0, k + 1);
+}
+
+std::vector<char> read_file(const std::string &path, size_t nbytes) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open buffer file " + path);
+    std::vector<char> data(nbytes);
+    f.read(data.data(), (std::streamsize)nbytes);
+    if ((size_t)f.gcount() != nbytes) throw std::runtime_error("buffer file shorter than byteLength: " + path);
+    return data;
+}
+
+float read_f32(const std::vector<char> &b, size_t off) {
+    if (off + 4 > b.size()) throw std::runtime_error("POSITION accessor reads past its buffer");
+    float v;
+    std::memcpy(&v, b.data() + off, 4);
+    return v;
+}
+
+size_t read_index(const std::vector<char> &b, size_t off, size_t width) {
+    if (off + width > b.size()) throw std::runtime_error("index accessor reads past its buffer");
+    if (width == 2) {
+        uint16_t v;
+        std::memcpy(&v, b.data() + off, 2);
+        return v;
+    }
+    uint32_t v;
+    std::memcpy(&v, b.data() + off, 4);
+    return v;
+}
+
+void load(const std::string &path, uint32_t width, uint32_t height, rt_host_scene &out) {
+    using jsonmin::Value;
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error("cannot open scene file " + path);
+    std::stringstream ss;
+    ss << in.rdbuf();
+    const Value data = jsonmin::parse(ss.str());
+    const std::string base = dir_of(path);
+
+    std::vector<std::vector<char>> buffers;  // main.cpp:874-882
+    for (const Value &b : data.at("buffers").a)
+        buffers.push_back(read_file(base + b.at("uri").as_string(), (size_t)b.at("byteLength").as_index()));
+
+    std::vector<BufferView> views;  // main.cpp:884-891
+    for (const Value &v : data.at("bufferViews").a) {
+        BufferView bv{(size_t)v.at("buffer").as_index(), (size_t)v.at("byteLength").as_index(),
+                      (size_t)v.at("byteOffset").as_index()};
+        if (bv.buffer >= buffers.size()) throw std::runtime_error("bufferView names a missing buffer");
+        views.push_back(bv);
+    }
+
+    out.materials.clear();  // main.cpp:893-927
+    if (data.contains("materials")) {
+        for (const Value &m : data.at("materials").a) {
+            rt_material md;
+            md.color[0] = md.color[1] = md.color[2] = 1.f;
+            md.emission[0] = md.emission[1] = md.emission[2] = 0.f;
+            md.type = RT_MAT_METALLIC;
+            md.ior = 1.5f;
+            if (m.contains("pbrMetallicRoughness")) {
+                const Value &r = m.at("pbrMetallicRoughness");
+                // The reference compares the JSON number (a double) with the float constant.
+                if (r.contains("metallicFactor") && r.at("metallicFactor").as_double() < (double)EPS)
+                    md.type = RT_MAT_DIFFUSER;
+                if (r.contains("baseColorFactor")) {
+                    const Value &c = r.at("baseColorFactor");
+                    md.color[0] = c.idx(0).as_float();
+                    md.color[1] = c.idx(1).as_float();
+                    md.color[2] = c.idx(2).as_float();
+                    if (c.idx(3).as_double() < (double)(1.f - EPS)) md.type = RT_MAT_DIELECTRIC;
+                }
+            }
+            if (m.contains("emissiveFactor")) {
+                const Value &e = m.at("emissiveFactor");
+                md.emission[0] = e.idx(0).as_float();
+                md.emission[1] = e.idx(1).as_float();
+                md.emission[2] = e.idx(2).as_float();
+            }
+            if (m.contains("extensions") && m.at("extensions").contains("KHR_materials_emissive_strength")) {
+                float strength =
+                    m.at("extensions").at("KHR_materials_emissive_strength").at("emissiveStrength").as_float();
+                md.emission[0] *= strength;
+                md.emission[1] *= strength;
+                md.emission[2] *= strength;
+            }
+            out.materials.push_back(md);
+        }
+    }
+
+    std::vector<std::vector<MeshPrimitive>> meshes;  // main.cpp:929-940
+    if (data.contains("meshes")) {
+        for (const Value &mesh : data.at("meshes").a) {
+            std::vector<MeshPrimitive> prims;
+            for (const Value &p : mesh.at("primitives").a)
+                prims.push_back(MeshPrimitive{(size_t)p.at("attributes").at("POSITION").as_index(),
+                                              (size_t)p.at("indices").as_index(),
+                                              (size_t)p.at("material").as_index()});
+            meshes.push_back(prims);
+        }
+    }
+
+    std::vector<Accessor> accessors;  // main.cpp:942-953
+    if (data.contains("accessors")) {
+        for (const Value &a : data.at("accessors").a) {
+            Accessor ad{(size_t)a.at("bufferView").as_index(), (size_t)a.at("count").as_index(),
+                        (size_t)a.at("componentType").as_index(), 0, a.at("type").as_string()};
+            if (a.contains("byteOffset")) ad.byteOffset = (size_t)a.at("byteOffset").as_index();
+            if (ad.bufferView >= views.size()) throw std::runtime_error("accessor names a missing bufferView");
+            accessors.push_back(ad);
+        }
+    }
+
+    rt_camera cam;
+    std::memset(&cam, 0, sizeof(cam));
+    hm::vec3 camRight = hm::V3(1.f, 0.f, 0.f), camUp = hm::V3(0.f, 1.f, 0.f), camFwd = hm::V3(0.f, 0.f, -1.f);
+    hm::vec3 camPos = hm::V3(0.f, 0.f, 0.f);
+    float tanY = 0.f;
+
+    const std::vector<Value> &nodes = data.at("nodes").a;
+    std::vector<hm::mat4> transitions;
+    std::vector<std::vector<size_t>> children;
+    for (const Value &node : nodes) {  // main.cpp:958-1020
+        hm::vec3 translation = hm::V3(0.f, 0.f, 0.f);
+        if (node.contains("translation")) {
+            const Value &t = node.at("translation");
+            translation = hm::V3(t.idx(0).as_float(), t.idx(1).as_float(), t.idx(2).as_float());
+        }
+        const float tvals[16] = {1.f, 0.f, 0.f, translation.x, 0.f, 1.f, 0.f, translation.y,
+                                 0.f, 0.f, 1.f, translation.z, 0.f, 0.f, 0.f, 1.f};
+        hm::mat4 translationMatrix = hm::mat4_from16(tvals);
+
+        hm::quat rotation{1.f, 0.f, 0.f, 0.f};
+        if (node.contains("rotation")) {
+            const Value &r = node.at("rotation");
+            rotation.x = r.idx(0).as_float();
+            rotation.y = r.idx(1).as_float();
+            rotation.z = r.idx(2).as_float();
+            rotation.w = r.idx(3).as_float();
+        }
+        hm::mat4 rotationMatrix = hm::transpose(hm::to_mat4(rotation));
+
+        hm::vec3 scale = hm::V3(1.f, 1.f, 1.f);
+        if (node.contains("scale")) {
+            const Value &s = node.at("scale");
+            scale = hm::V3(s.idx(0).as_float(), s.idx(1).as_float(), s.idx(2).as_float());
+        }
+        const float svals[16] = {scale.x, 0.f, 0.f, 0.f, 0.f, scale.y, 0.f, 0.f,
+                                 0.f, 0.f, scale.z, 0.f, 0.f, 0.f, 0.f, 1.f};
+        hm::mat4 scaleMat = hm::mat4_from16(svals);
+
+        hm::mat4 transition = hm::transpose(scaleMat * rotationMatrix * translationMatrix);
+        if (node.contains("matrix")) {
+            const Value &mv = node.at("matrix");
+            for (int i = 0; i < 16; ++i) hm::elem(transition.c[i / 4], i % 4) = mv.idx((size_t)i).as_float();
+        }
+        translation = hm::V3(transition.c[3].x, transition.c[3].y, transition.c[3].z);
+        rotation = hm::to_quat(transition);
+        transitions.push_back(transition);
+
+        std::vector<size_t> ch;
+        if (node.contains("children"))
+            for (const Value &c : node.at("children").a) {
+                size_t k = (size_t)c.as_index();
+                if (k >= nodes.size()) throw std::runtime_error("node child index out of range");
+                ch.push_back(k);
+            }
+        children.push_back(ch);
+
+        if (node.contains("camera")) {  // main.cpp:1012-1019
+            float yfov = data.at("cameras").idx((size_t)node.at("camera").as_index()).at("perspective")
+                             .at("yfov").as_float();
+            tanY = std::tan(yfov / 2.f);
+            camPos = translation;
+            camRight = hm::rotate(rotation, camRight);
+            camUp = hm::rotate(rotation, camUp);
+            camFwd = hm::rotate(rotation, camFwd);
+        }
+    }
+
+    for (size_t i = 0; i < transitions.size(); ++i)  // main.cpp:1022-1026
+        for (size_t child : children[i]) transitions[child] = transitions[i] * transitions[child];
+
+    out.tri_verts.clear();
+    out.tri_material.clear();
+    for (size_t i = 0; i < transitions.size(); ++i) {  // main.cpp:1028-1101
+        if (!nodes[i].contains("mesh")) continue;
+        size_t meshIdx = (size_t)nodes[i].at("mesh").as_index();
+        if (meshIdx >= meshes.size()) throw std::runtime_error("node names a missing mesh");
+        for (const MeshPrimitive &prim : meshes[meshIdx]) {
+            if (prim.position >= accessors.size() || prim.indices >= accessors.size())
+                throw std::runtime_error("mesh primitive names a missing accessor");
+            if (prim.material >= out.materials.size())
+                throw std::runtime_error("mesh primitive names a missing material");
+            const Accessor &ap = accessors[prim.position];
+            const BufferView &vp = views[ap.bufferView];
+            const std::vector<char> &bp = buffers[vp.buffer];
+            if (ap.type != "VEC3") throw std::runtime_error("Unsupported accessor type, expected VEC3");
+            const size_t offset = vp.byteOffset + ap.byteOffset;
+            std::vector<hm::vec3> points(ap.count);
+            for (size_t j = 0; j < ap.count; ++j)
+                points[j] = hm::V3(read_f32(bp, offset + 12 * j), read_f32(bp, offset + 12 * j + 4),
+                                   read_f32(bp, offset + 12 * j + 8));
+
+            const Accessor &ai = accessors[prim.indices];
+            const BufferView &vi = views[ai.bufferView];
+            const std::vector<char> &bi = buffers[vi.buffer];
+            if (ai.type != "SCALAR") throw std::runtime_error("Unsupported accessor type, expected SCALAR");
+            size_t iw;
+            if (ai.componentType == 5123) iw = 2;
+            else if (ai.componentType == 5125) iw = 4;
+            else throw std::runtime_error("Unsupported accessor component type, expected 5123 or 5125");
+
+            const hm::mat4 &m = transitions[i];
+            for (size_t j = 0; j < ai.count; j += 3) {
+                size_t idx[3];
+                for (size_t k = 0; k < 3; ++k) {
+                    idx[k] = read_index(bi, vi.byteOffset + iw * (j + k), iw);
+                    if (idx[k] >= points.size()) throw std::runtime_error("vertex index out of range");
+                }
+                for (size_t k = 0; k < 3; ++k) {
+                    const hm::vec3 &p = points[idx[k]];
+                    hm::vec4 w = m * hm::vec4{p.x, p.y, p.z, 1.f};
+                    out.tri_verts.push_back(w.x);
+                    out.tri_verts.push_back(w.y);
+                    out.tri_verts.push_back(w.z);
+                }
+                out.tri_material.push_back((uint32_t)prim.material);
+            }
+        }
+    }
+
+    for (int k = 0; k < 3; ++k) {
+        cam.position[k] = (&camPos.x)[k];
+        cam.right[k] = (&camRight.x)[k];
+        cam.up[k] = (&camUp.x)[k];
+        cam.forward[k] = (&camFwd.x)[k];
+    }
+    cam.tan_y = tanY;
+    cam.tan_x = tanY * float(width) / float(height);  // main.cpp:1104
+    out.camera = cam;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_gltf_load(const char *path, uint32_t width, uint32_t height, rt_host_scene **out) {
+    if (!path || !out || width == 0 || height == 0) {
+        rt::set_error("rt_gltf_load: null argument or zero image size");
+        return RT_ERR_INVALID;
+    }
+    *out = nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    rt_host_scene *hs = nullptr;
+    try {
+        hs = new rt_host_scene();
+        load(path, width, height, *hs);
+    } catch (const std::exception &e) {
+        delete hs;
+        rt::set_error(std::string("rt_gltf_load: ") + e.what());
+        std::string msg = e.what();
+        return (msg.rfind("cannot open", 0) == 0 || msg.rfind("buffer file", 0) == 0) ? RT_ERR_IO : RT_ERR_INVALID;
+    }
+    hs->parse_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *out = hs;
+    return RT_OK;
+}
+
+int rt_host_scene_get_desc(const rt_host_scene *hs, rt_scene_desc *out) {
+    if (!hs || !out) {
+        rt::set_error("rt_host_scene_get_desc: null argument");
+        return RT_ERR_INVALID;
+    }
+    out->tri_verts = hs->tri_verts.data();
+    out->tri_material = hs->tri_material.data();
+    out->ntri = (uint32_t)hs->tri_material.size();
+    out->materials = hs->materials.data();
+    out->nmat = (uint32_t)hs->materials.size();
+    out->camera = hs->camera;
+    return RT_OK;
+}
+
+void rt_host_scene_free(rt_host_scene *hs) { delete hs; }
+
+}  // extern "C"

@@ -1,0 +1,125 @@
+// raytracing_cli.cpp -- the command-line host.  Keeps the reference's contract
+// (main.cpp:1244-1259, run.sh:1):
+//
+//     raytracing <scene.gltf> <width> <height> <samples> <output.ppm> [options]
+//
+// writes a binary PPM (P6) and prints the two timing lines of the reference
+// ("Processed input after ...s", "Finished after ...s").  Options after the five positionals:
+//     --depth N        maximum path depth (default 6, the reference's rayDepth, main.cpp:692)
+//     --rng MODE       reference | counter   (default reference: one minstd_rand stream per pixel)
+//     --pipeline P     mega | wavefront      (default mega; wavefront needs --rng counter)
+//     --seed S         seed of the counter RNG (default 0)
+//     --device D       GPU index (default 0)
+//     --dump-hits F    also write the primary-ray closest hits (uint32 id, float t per pixel) to F
+// All rendering runs on the GPU through the C ABI of librt_amd.so; there is no CPU fallback.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+
+static double now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static int die(const char *what) {
+    std::fprintf(stderr, "raytracing: %s: %s\n", what, rt_last_error());
+    return 1;
+}
+
+int main(int argc, char *argv[]) {
+    const double start = now();
+    if (argc < 6) {
+        std::fprintf(stderr,
+                     "usage: %s <scene.gltf> <width> <height> <samples> <output.ppm> [--depth N] [--rng reference|counter]"
+                     " [--pipeline mega|wavefront] [--seed S] [--device D] [--dump-hits FILE]\n",
+                     argv[0]);
+        return 2;
+    }
+    const std::string inputPath = argv[1], outputPath = argv[5];
+    const long width = std::atol(argv[2]), height = std::atol(argv[3]), samples = std::atol(argv[4]);
+    if (width <= 0 || height <= 0 || samples <= 0 || width > 65535 || height > 65535) {
+        std::fprintf(stderr, "raytracing: width, height and samples must be positive (width/height at most 65535)\n");
+        return 2;
+    }
+    uint32_t depth = 6, seed = 0;
+    int rng = RT_RNG_REFERENCE, pipeline = RT_PIPE_MEGAKERNEL, device = 0;
+    std::string dumpHits;
+    for (int i = 6; i < argc; ++i) {
+        std::string a = argv[i];
+        auto need = [&](const char *name) -> const char * {
+            if (i + 1 >= argc) {
+                std::fprintf(stderr, "raytracing: %s needs a value\n", name);
+                std::exit(2);
+            }
+            return argv[++i];
+        };
+        if (a == "--depth") depth = (uint32_t)std::atol(need("--depth"));
+        else if (a == "--seed") seed = (uint32_t)std::strtoul(need("--seed"), nullptr, 0);
+        else if (a == "--device") device = std::atoi(need("--device"));
+        else if (a == "--dump-hits") dumpHits = need("--dump-hits");
+        else if (a == "--rng") {
+            std::string v = need("--rng");
+            if (v == "reference") rng = RT_RNG_REFERENCE;
+            else if (v == "counter") rng = RT_RNG_COUNTER;
+            else {
+                std::fprintf(stderr, "raytracing: --rng must be reference or counter\n");
+                return 2;
+            }
+        } else if (a == "--pipeline") {
+            std::string v = need("--pipeline");
+            if (v == "mega") pipeline = RT_PIPE_MEGAKERNEL;
+            else if (v == "wavefront") pipeline = RT_PIPE_WAVEFRONT;
+            else {
+                std::fprintf(stderr, "raytracing: --pipeline must be mega or wavefront\n");
+                return 2;
+            }
+        } else {
+            std::fprintf(stderr, "raytracing: unknown option %s\n", a.c_str());
+            return 2;
+        }
+    }
+
+    rt_host_scene *hs = nullptr;
+    if (rt_gltf_load(inputPath.c_str(), (uint32_t)width, (uint32_t)height, &hs) != RT_OK) return die("loading the scene");
+    rt_scene_desc desc;
+    rt_host_scene_get_desc(hs, &desc);
+    rt_scene *scene = nullptr;
+    if (rt_scene_create(&desc, device, &scene) != RT_OK) return die("uploading the scene");
+    rt_host_scene_free(hs);
+    std::printf("Processed input after %gs\n", now() - start);
+
+    const size_t npix = (size_t)width * height;
+    if (!dumpHits.empty()) {
+        std::vector<uint32_t> ids(npix);
+        std::vector<float> ts(npix);
+        if (rt_trace_primary(scene, (uint32_t)width, (uint32_t)height, ids.data(), ts.data()) != RT_OK) return die("tracing primary rays");
+        FILE *f = std::fopen(dumpHits.c_str(), "wb");
+        if (!f) {
+            std::fprintf(stderr, "raytracing: cannot open %s\n", dumpHits.c_str());
+            return 1;
+        }
+        std::fwrite(ids.data(), 4, npix, f);
+        std::fwrite(ts.data(), 4, npix, f);
+        std::fclose(f);
+    }
+
+    std::vector<float> sum(npix * 3);
+    const double t0 = now();
+    if (rt_render(scene, (uint32_t)width, (uint32_t)height, 0, (uint32_t)samples, depth, rng, seed, pipeline, sum.data()) != RT_OK)
+        return die("rendering");
+    const double renderSeconds = now() - t0;
+    std::vector<uint8_t> rgb(npix * 3);
+    if (rt_tonemap(scene, sum.data(), npix, (uint32_t)samples, nullptr, rgb.data()) != RT_OK) return die("tone mapping");
+    if (rt_write_ppm(outputPath.c_str(), (uint32_t)width, (uint32_t)height, rgb.data()) != RT_OK) return die("writing the image");
+    rt_counters c;
+    if (rt_counters_read(scene, &c) == RT_OK && renderSeconds > 0)
+        std::printf("Traced %llu ray segments in %gs (%.1f Mrays/s)\n", (unsigned long long)c.segments, renderSeconds,
+                    (double)c.segments / renderSeconds * 1e-6);
+    rt_scene_destroy(scene);
+    std::printf("Finished after %gs", now() - start);
+    return 0;
+}

@@ -1,0 +1,426 @@
+// rt_abi.hip -- the extern "C" boundary of librt_amd.so (declared in include/rt_amd.h):
+// scene upload, argument checks, launches, host-pointer convenience wrappers.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <new>
+#include <stdexcept>
+#include <string>
+
+#include "rt_internal.h"
+#include "rt_launch.h"
+
+namespace rt {
+static thread_local std::string g_error;
+void set_error(const std::string &msg) { g_error = msg; }
+}  // namespace rt
+
+struct rt_scene {
+    int device = 0;
+    rt::FlatScene flat;
+    rtd::DevScene view{};
+    float4 *d_nodes = nullptr;
+    float4 *d_tris = nullptr;
+    uint32_t *d_lights = nullptr;
+    rtd::DevMaterial *d_mats = nullptr;
+    unsigned long long *d_counters = nullptr;
+    rt::WavefrontBuffers wf;
+    uint64_t device_bytes = 0;
+    bool counting = false;
+    uint32_t nmat = 0;
+};
+
+namespace {
+
+struct DeviceGuard {  // makes the scene's GPU current for the call, restores the caller's on exit
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+int fail(int code, const std::string &msg) {
+    rt::set_error(msg);
+    return code;
+}
+
+int hip_fail(const char *what, hipError_t e) {
+    return fail(RT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define RT_HIP(call)                                  \
+    do {                                              \
+        hipError_t e__ = (call);                      \
+        if (e__ != hipSuccess) return hip_fail(#call, e__); \
+    } while (0)
+
+template <typename T>
+hipError_t dev_alloc(rt_scene *s, T **p, size_t count) {
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    hipError_t e = hipMalloc((void **)p, bytes);
+    if (e == hipSuccess) s->device_bytes += bytes;
+    return e;
+}
+
+void free_wavefront(rt_scene *s) {
+    rt::WavefrontBuffers &w = s->wf;
+    (void)hipFree(w.ray);
+    (void)hipFree(w.thr);
+    (void)hipFree(w.rad);
+    (void)hipFree(w.rng);
+    (void)hipFree(w.meta);
+    (void)hipFree(w.hit_t);
+    (void)hipFree(w.hit_tri);
+    (void)hipFree(w.queue[0]);
+    (void)hipFree(w.queue[1]);
+    (void)hipFree(w.qcount);
+    w = rt::WavefrontBuffers();
+}
+
+// Path records in flight per wavefront pass: whole frames of samples, about 4M paths.
+int ensure_wavefront(rt_scene *s, uint32_t npix) {
+    const uint64_t target = 4u << 20;
+    uint64_t slots = target / npix;
+    if (slots < 1) slots = 1;
+    if (slots > 64) slots = 64;
+    const uint64_t cap64 = slots * npix;
+    if (cap64 > 0x7FFFFFFFull) return fail(RT_ERR_LIMIT, "wavefront pipeline: image too large");
+    const uint32_t cap = (uint32_t)cap64;
+    if (s->wf.capacity == cap) return RT_OK;
+    free_wavefront(s);
+    rt::WavefrontBuffers &w = s->wf;
+    RT_HIP(dev_alloc(s, &w.ray, (size_t)cap * 6));
+    RT_HIP(dev_alloc(s, &w.thr, (size_t)cap * 3));
+    RT_HIP(dev_alloc(s, &w.rad, (size_t)cap * 3));
+    RT_HIP(dev_alloc(s, &w.rng, (size_t)cap));
+    RT_HIP(dev_alloc(s, &w.meta, (size_t)cap));
+    RT_HIP(dev_alloc(s, &w.hit_t, (size_t)cap));
+    RT_HIP(dev_alloc(s, &w.hit_tri, (size_t)cap));
+    RT_HIP(dev_alloc(s, &w.queue[0], (size_t)cap));
+    RT_HIP(dev_alloc(s, &w.queue[1], (size_t)cap));
+    RT_HIP(dev_alloc(s, &w.qcount, (size_t)4));
+    RT_HIP(hipMemset(w.qcount, 0, 4 * sizeof(uint32_t)));
+    w.capacity = cap;
+    return RT_OK;
+}
+
+int check_image(uint32_t W, uint32_t H) {
+    if (W == 0 || H == 0) return fail(RT_ERR_INVALID, "image width and height must be positive");
+    if ((uint64_t)W * H > (1ull << 28)) return fail(RT_ERR_LIMIT, "image has more than 2^28 pixels");
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return rt::g_error.c_str(); }
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+uint32_t rt_counter_seed(uint32_t pixel, uint32_t sample, uint32_t seed) { return rtd::counter_seed(pixel, sample, seed); }
+
+int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
+    if (!desc || !out) return fail(RT_ERR_INVALID, "rt_scene_create: null argument");
+    *out = nullptr;
+    int ndev = rt_device_count();
+    if (ndev <= 0) return fail(RT_ERR_HIP, "rt_scene_create: no HIP device is visible");
+    if (device < 0 || device >= ndev) return fail(RT_ERR_INVALID, "rt_scene_create: device index out of range");
+    rt_scene *s = new (std::nothrow) rt_scene();
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_create: out of host memory");
+    s->device = device;
+    try {
+        rt::build_flat_scene(*desc, s->flat);
+    } catch (const std::exception &e) {
+        delete s;
+        std::string msg = e.what();
+        return fail(msg.find("too many") != std::string::npos ? RT_ERR_LIMIT : RT_ERR_INVALID,
+                    "rt_scene_create: " + msg);
+    }
+    if (s->flat.tree_height > rt::kStackEntries) {
+        delete s;
+        return fail(RT_ERR_LIMIT, "rt_scene_create: BVH height exceeds the kernels' traversal stack");
+    }
+    DeviceGuard g(device);
+    if (!g.ok) {
+        delete s;
+        return fail(RT_ERR_HIP, "rt_scene_create: hipSetDevice failed");
+    }
+    const rt::FlatScene &f = s->flat;
+    std::vector<rtd::DevMaterial> mats(desc->nmat ? desc->nmat : 1);
+    for (uint32_t i = 0; i < desc->nmat; ++i) {
+        const rt_material &m = desc->materials[i];
+        if (m.type < 0 || m.type > 2) {
+            delete s;
+            return fail(RT_ERR_INVALID, "rt_scene_create: material type must be 0, 1 or 2");
+        }
+        float tbits;
+        int32_t ty = m.type;
+        std::memcpy(&tbits, &ty, 4);
+        mats[i].a = make_float4(m.color[0], m.color[1], m.color[2], tbits);
+        mats[i].b = make_float4(m.emission[0], m.emission[1], m.emission[2], m.ior);
+    }
+    s->nmat = desc->nmat;
+    hipError_t e;
+#define RT_TRY(call)                       \
+    if ((e = (call)) != hipSuccess) {      \
+        int rc = hip_fail(#call, e);       \
+        rt_scene_destroy(s);               \
+        return rc;                         \
+    }
+    RT_TRY(dev_alloc(s, &s->d_nodes, f.nodes.size() / 4));
+    RT_TRY(dev_alloc(s, &s->d_tris, f.tris.size() / 4));
+    RT_TRY(dev_alloc(s, &s->d_lights, f.lights.size()));
+    RT_TRY(dev_alloc(s, &s->d_mats, mats.size()));
+    RT_TRY(dev_alloc(s, &s->d_counters, (size_t)8));
+    RT_TRY(hipMemcpy(s->d_nodes, f.nodes.data(), f.nodes.size() * sizeof(float), hipMemcpyHostToDevice));
+    RT_TRY(hipMemcpy(s->d_tris, f.tris.data(), f.tris.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!f.lights.empty())
+        RT_TRY(hipMemcpy(s->d_lights, f.lights.data(), f.lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    RT_TRY(hipMemcpy(s->d_mats, mats.data(), mats.size() * sizeof(rtd::DevMaterial), hipMemcpyHostToDevice));
+    RT_TRY(hipMemset(s->d_counters, 0, 8 * sizeof(unsigned long long)));
+#undef RT_TRY
+    rtd::DevScene &v = s->view;
+    v.nodes = s->d_nodes;
+    v.tris = s->d_tris;
+    v.lights = s->d_lights;
+    v.mats = s->d_mats;
+    v.counters = s->d_counters;
+    v.nlights = (uint32_t)f.lights.size();
+    for (int k = 0; k < 3; ++k) {
+        v.cam_pos[k] = desc->camera.position[k];
+        v.cam_right[k] = desc->camera.right[k];
+        v.cam_up[k] = desc->camera.up[k];
+        v.cam_fwd[k] = desc->camera.forward[k];
+    }
+    v.tan_x = desc->camera.tan_x;
+    v.tan_y = desc->camera.tan_y;
+    *out = s;
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene *s) {
+    if (!s) return;
+    DeviceGuard g(s->device);
+    free_wavefront(s);
+    (void)hipFree(s->d_nodes);
+    (void)hipFree(s->d_tris);
+    (void)hipFree(s->d_lights);
+    (void)hipFree(s->d_mats);
+    (void)hipFree(s->d_counters);
+    delete s;
+}
+
+int rt_scene_get_stats(const rt_scene *s, rt_scene_stats *out) {
+    if (!s || !out) return fail(RT_ERR_INVALID, "rt_scene_get_stats: null argument");
+    out->ntri = s->flat.ntri;
+    out->nlights = (uint32_t)s->flat.lights.size();
+    out->nnodes = s->flat.nnodes;
+    out->tree_height = s->flat.tree_height;
+    out->build_seconds = s->flat.build_seconds;
+    out->device_bytes = s->device_bytes;
+    return RT_OK;
+}
+
+int rt_scene_get_flat(const rt_scene *s, float *nodes, float *tris) {
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_get_flat: null scene");
+    if (nodes) std::memcpy(nodes, s->flat.nodes.data(), (size_t)s->flat.nnodes * 16 * sizeof(float));
+    if (tris) std::memcpy(tris, s->flat.tris.data(), (size_t)s->flat.ntri * 16 * sizeof(float));
+    return RT_OK;
+}
+
+int rt_intersect_rays_dev(rt_scene *s, uint64_t n, const float *d_origins, const float *d_directions,
+                          uint32_t *d_prim_id, float *d_t, void *stream) {
+    if (!s) return fail(RT_ERR_INVALID, "rt_intersect_rays_dev: null scene");
+    if (n == 0) return RT_OK;
+    if (!d_origins || !d_directions || !d_prim_id || !d_t) return fail(RT_ERR_INVALID, "rt_intersect_rays_dev: null buffer");
+    if (n > (1ull << 31)) return fail(RT_ERR_LIMIT, "rt_intersect_rays_dev: more than 2^31 rays in one call");
+    DeviceGuard g(s->device);
+    RT_HIP(rt::launch_intersect(s->view, n, d_origins, d_directions, d_prim_id, d_t, s->counting, (hipStream_t)stream));
+    return RT_OK;
+}
+
+int rt_intersect_rays(rt_scene *s, uint64_t n, const float *origins, const float *directions, uint32_t *prim_id,
+                      float *t) {
+    if (!s) return fail(RT_ERR_INVALID, "rt_intersect_rays: null scene");
+    if (n == 0) return RT_OK;
+    if (!origins || !directions || !prim_id || !t) return fail(RT_ERR_INVALID, "rt_intersect_rays: null buffer");
+    DeviceGuard g(s->device);
+    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
+    uint32_t *d_id = nullptr;
+    int rc = RT_OK;
+    hipError_t e = hipSuccess;
+    if ((e = hipMalloc((void **)&d_o, n * 12)) == hipSuccess && (e = hipMalloc((void **)&d_d, n * 12)) == hipSuccess &&
+        (e = hipMalloc((void **)&d_t, n * 4)) == hipSuccess && (e = hipMalloc((void **)&d_id, n * 4)) == hipSuccess &&
+        (e = hipMemcpy(d_o, origins, n * 12, hipMemcpyHostToDevice)) == hipSuccess &&
+        (e = hipMemcpy(d_d, directions, n * 12, hipMemcpyHostToDevice)) == hipSuccess) {
+        rc = rt_intersect_rays_dev(s, n, d_o, d_d, d_id, d_t, nullptr);
+        if (rc == RT_OK && (e = hipDeviceSynchronize()) == hipSuccess &&
+            (e = hipMemcpy(prim_id, d_id, n * 4, hipMemcpyDeviceToHost)) == hipSuccess)
+            e = hipMemcpy(t, d_t, n * 4, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_o);
+    (void)hipFree(d_d);
+    (void)hipFree(d_t);
+    (void)hipFree(d_id);
+    if (e != hipSuccess) return hip_fail("rt_intersect_rays", e);
+    return rc;
+}
+
+int rt_trace_primary_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t *d_prim_id, float *d_t, void *stream) {
+    if (!s || !d_prim_id || !d_t) return fail(RT_ERR_INVALID, "rt_trace_primary_dev: null argument");
+    int rc = check_image(width, height);
+    if (rc != RT_OK) return rc;
+    DeviceGuard g(s->device);
+    RT_HIP(rt::launch_primary(s->view, width, height, d_prim_id, d_t, s->counting, (hipStream_t)stream));
+    return RT_OK;
+}
+
+int rt_trace_primary(rt_scene *s, uint32_t width, uint32_t height, uint32_t *prim_id, float *t) {
+    if (!s || !prim_id || !t) return fail(RT_ERR_INVALID, "rt_trace_primary: null argument");
+    int rc = check_image(width, height);
+    if (rc != RT_OK) return rc;
+    DeviceGuard g(s->device);
+    const size_t n = (size_t)width * height;
+    uint32_t *d_id = nullptr;
+    float *d_t = nullptr;
+    hipError_t e = hipSuccess;
+    if ((e = hipMalloc((void **)&d_id, n * 4)) == hipSuccess && (e = hipMalloc((void **)&d_t, n * 4)) == hipSuccess) {
+        rc = rt_trace_primary_dev(s, width, height, d_id, d_t, nullptr);
+        if (rc == RT_OK && (e = hipDeviceSynchronize()) == hipSuccess &&
+            (e = hipMemcpy(prim_id, d_id, n * 4, hipMemcpyDeviceToHost)) == hipSuccess)
+            e = hipMemcpy(t, d_t, n * 4, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_id);
+    (void)hipFree(d_t);
+    if (e != hipSuccess) return hip_fail("rt_trace_primary", e);
+    return rc;
+}
+
+int rt_render_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_begin, uint32_t spp_count,
+                  uint32_t max_depth, int rng_mode, uint32_t seed, int pipeline, float *d_radiance_sum, void *stream) {
+    if (!s || !d_radiance_sum) return fail(RT_ERR_INVALID, "rt_render_dev: null argument");
+    int rc = check_image(width, height);
+    if (rc != RT_OK) return rc;
+    if (rng_mode != RT_RNG_REFERENCE && rng_mode != RT_RNG_COUNTER) return fail(RT_ERR_INVALID, "rt_render_dev: unknown rng_mode");
+    if (rng_mode == RT_RNG_REFERENCE && spp_begin != 0)
+        return fail(RT_ERR_INVALID, "rt_render_dev: the reference RNG stream is carried across a pixel's samples, spp_begin must be 0");
+    if (pipeline != RT_PIPE_MEGAKERNEL && pipeline != RT_PIPE_WAVEFRONT) return fail(RT_ERR_INVALID, "rt_render_dev: unknown pipeline");
+    if (pipeline == RT_PIPE_WAVEFRONT && rng_mode != RT_RNG_COUNTER)
+        return fail(RT_ERR_INVALID, "rt_render_dev: the wavefront pipeline needs RT_RNG_COUNTER (samples of a pixel run concurrently)");
+    if (max_depth > 65535u) return fail(RT_ERR_LIMIT, "rt_render_dev: max_depth above 65535");
+    if ((uint64_t)spp_begin + spp_count > 0xFFFFFFFFull) return fail(RT_ERR_LIMIT, "rt_render_dev: sample range overflows 32 bits");
+    DeviceGuard g(s->device);
+    rt::RenderParams rp{width, height, spp_begin, spp_count, max_depth, rng_mode, seed};
+    if (pipeline == RT_PIPE_MEGAKERNEL) {
+        RT_HIP(rt::launch_render_mega(s->view, rp, d_radiance_sum, s->counting, (hipStream_t)stream));
+    } else {
+        rc = ensure_wavefront(s, width * height);
+        if (rc != RT_OK) return rc;
+        RT_HIP(rt::launch_render_wavefront(s->view, rp, d_radiance_sum, s->wf, s->counting, (hipStream_t)stream));
+    }
+    return RT_OK;
+}
+
+int rt_render(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
+              int rng_mode, uint32_t seed, int pipeline, float *radiance_sum) {
+    if (!s || !radiance_sum) return fail(RT_ERR_INVALID, "rt_render: null argument");
+    int rc = check_image(width, height);
+    if (rc != RT_OK) return rc;
+    DeviceGuard g(s->device);
+    const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+    float *d_sum = nullptr;
+    hipError_t e = hipMalloc((void **)&d_sum, bytes);
+    if (e != hipSuccess) return hip_fail("rt_render: hipMalloc", e);
+    rc = rt_render_dev(s, width, height, spp_begin, spp_count, max_depth, rng_mode, seed, pipeline, d_sum, nullptr);
+    if (rc == RT_OK && (e = hipDeviceSynchronize()) == hipSuccess) e = hipMemcpy(radiance_sum, d_sum, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d_sum);
+    if (e != hipSuccess) return hip_fail("rt_render", e);
+    return rc;
+}
+
+int rt_tonemap_dev(rt_scene *s, const float *d_radiance_sum, uint64_t npixels, uint32_t spp, float *d_out_float,
+                   uint8_t *d_out_rgb, void *stream) {
+    if (!s || !d_radiance_sum) return fail(RT_ERR_INVALID, "rt_tonemap_dev: null argument");
+    if (spp == 0) return fail(RT_ERR_INVALID, "rt_tonemap_dev: spp must be positive");
+    DeviceGuard g(s->device);
+    RT_HIP(rt::launch_tonemap(d_radiance_sum, npixels, spp, d_out_float, d_out_rgb, (hipStream_t)stream));
+    return RT_OK;
+}
+
+int rt_tonemap(rt_scene *s, const float *radiance_sum, uint64_t npixels, uint32_t spp, float *out_float, uint8_t *out_rgb) {
+    if (!s || !radiance_sum) return fail(RT_ERR_INVALID, "rt_tonemap: null argument");
+    if (npixels == 0) return RT_OK;
+    DeviceGuard g(s->device);
+    const size_t n3 = (size_t)npixels * 3;
+    float *d_sum = nullptr, *d_f = nullptr;
+    uint8_t *d_b = nullptr;
+    int rc = RT_OK;
+    hipError_t e = hipSuccess;
+    if ((e = hipMalloc((void **)&d_sum, n3 * 4)) == hipSuccess && (e = hipMalloc((void **)&d_f, n3 * 4)) == hipSuccess &&
+        (e = hipMalloc((void **)&d_b, n3)) == hipSuccess &&
+        (e = hipMemcpy(d_sum, radiance_sum, n3 * 4, hipMemcpyHostToDevice)) == hipSuccess) {
+        rc = rt_tonemap_dev(s, d_sum, npixels, spp, d_f, d_b, nullptr);
+        if (rc == RT_OK && (e = hipDeviceSynchronize()) == hipSuccess) {
+            if (out_float) e = hipMemcpy(out_float, d_f, n3 * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && out_rgb) e = hipMemcpy(out_rgb, d_b, n3, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(d_sum);
+    (void)hipFree(d_f);
+    (void)hipFree(d_b);
+    if (e != hipSuccess) return hip_fail("rt_tonemap", e);
+    return rc;
+}
+
+// printImage, main.cpp:856-864: "P6\n<W> <H>\n255\n" followed by W*H RGB bytes, top row first.
+int rt_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb) {
+    if (!path || !rgb) return fail(RT_ERR_INVALID, "rt_write_ppm: null argument");
+    std::ofstream f(path, std::ios::binary);
+    if (!f) return fail(RT_ERR_IO, std::string("rt_write_ppm: cannot open ") + path);
+    f << "P6" << '\n' << width << " " << height << '\n' << 255 << '\n';
+    f.write(reinterpret_cast<const char *>(rgb), (std::streamsize)((size_t)width * height * 3));
+    f.close();
+    if (!f) return fail(RT_ERR_IO, std::string("rt_write_ppm: write failed for ") + path);
+    return RT_OK;
+}
+
+int rt_set_counting(rt_scene *s, int enable) {
+    if (!s) return fail(RT_ERR_INVALID, "rt_set_counting: null scene");
+    s->counting = enable != 0;
+    return RT_OK;
+}
+
+int rt_counters_reset(rt_scene *s, void *stream) {
+    if (!s) return fail(RT_ERR_INVALID, "rt_counters_reset: null scene");
+    DeviceGuard g(s->device);
+    RT_HIP(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), (hipStream_t)stream));
+    return RT_OK;
+}
+
+int rt_counters_read(rt_scene *s, rt_counters *out) {
+    if (!s || !out) return fail(RT_ERR_INVALID, "rt_counters_read: null argument");
+    DeviceGuard g(s->device);
+    unsigned long long h[4];
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpy(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    out->segments = h[0];
+    out->nodes = h[1];
+    out->tri_tests = h[2];
+    out->light_tests = h[3];
+    return RT_OK;
+}
+
+}  // extern "C"

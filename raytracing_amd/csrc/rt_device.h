@@ -1,0 +1,381 @@
+// rt_device.h -- device-side building blocks of the gfx950 path tracer: fp32 vector math in
+// the reference's operation order, the minstd_rand / libstdc++ distribution restatements, the
+// exact-arithmetic ray/triangle test, the conservative ray/box slab test, stack traversal of
+// the 64-byte two-child BVH nodes, and one shading step of the reference's estimator.
+//
+// Everything here is compiled with -ffp-contract=off: results that decide which triangle a ray
+// hits must not depend on fused multiply-adds, because the reference is built for x86-64
+// without FMA (CMakeLists.txt:4, build.sh:3) and the closest-hit ids are compared bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtd {
+
+constexpr float kEps = 0.0001f;    // EPS, main.cpp:22
+constexpr float kInf = 10000.f;    // INF, main.cpp:23
+constexpr float kOneOverPi = 0.318309886183790671537767526745028724f;  // glm::one_over_pi<float>()
+constexpr int kBlock = 256;        // threads per workgroup of every traversal kernel (4 waves)
+constexpr int kStack = 32;         // traversal stack entries per lane (host checks tree height)
+
+// ---------------------------------------------------------------------------------------------
+// vec3 in glm 0.9.9.8 operation order (one rounding per operation, sums left to right)
+// ---------------------------------------------------------------------------------------------
+struct v3 {
+    float x, y, z;
+};
+__device__ __forceinline__ v3 mk(float x, float y, float z) { return v3{x, y, z}; }
+__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 operator*(v3 a, v3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ v3 operator*(v3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ v3 operator*(float s, v3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ v3 operator-(v3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ v3 normalize(v3 v) { return v * (1.f / __builtin_sqrtf(dot(v, v))); }
+
+// ---------------------------------------------------------------------------------------------
+// RNG: std::minstd_rand and the libstdc++ 11 distributions the reference instantiates per call
+// (main.cpp:98-111).  Engine: x <- 48271 x mod (2^31 - 1); seed s -> s mod m, 0 -> 1.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rng_seed(uint32_t s) {
+    uint32_t x = s % 2147483647u;
+    return x == 0u ? 1u : x;
+}
+__device__ __forceinline__ uint32_t rng_next(uint32_t &x) {
+    uint64_t p = (uint64_t)x * 48271u;
+    uint32_t r = (uint32_t)(p & 0x7FFFFFFFu) + (uint32_t)(p >> 31);
+    if (r >= 2147483647u) r -= 2147483647u;
+    x = r;
+    return r;
+}
+// uniform_real_distribution<float>(0,1): generate_canonical<float,24> draws once;
+// float(x - 1) / 2^31 (the engine range 2147483646 rounds to 2^31 in fp32), clamped below 1.
+__device__ __forceinline__ float rng_uniform(uint32_t &x) {
+    float u = (float)(rng_next(x) - 1u) * 4.656612873077392578125e-10f;  // exact scaling by 2^-31
+    if (u >= 1.f) u = 0.99999994f;                                      // nextafter(1, 0)
+    return u;
+}
+// uniform_int_distribution<uint16_t>(0, L-1) over an engine range of 2147483645: the generic
+// down-scaling branch (two divisions, rejection above L * scaling).
+__device__ __forceinline__ uint32_t rng_uint(uint32_t &x, uint32_t L) {
+    const uint32_t scaling = 2147483645u / L;
+    const uint32_t past = L * scaling;
+    uint32_t r;
+    do {
+        r = rng_next(x) - 1u;
+    } while (r >= past);
+    return r / scaling;
+}
+
+// Natural logarithm of a float in (0, 1] for the polar method below (std::log(float)).
+__device__ __forceinline__ float rng_logf(float v) { return __builtin_logf(v); }
+
+// normal_distribution<float>(0,1), Marsaglia polar; the distribution object is a temporary in
+// the reference, so its cached second variate is discarded and every call runs the loop and
+// returns y * mult.
+__device__ __forceinline__ float rng_normal(uint32_t &x) {
+    float a, b, r2;
+    do {
+        a = 2.0f * rng_uniform(x) - 1.0f;
+        b = 2.0f * rng_uniform(x) - 1.0f;
+        r2 = a * a + b * b;
+    } while (r2 > 1.0f || r2 == 0.0f);
+    const float mult = __builtin_sqrtf(-2.f * rng_logf(r2) / r2);
+    return b * mult;
+}
+
+// Seed of the per-(pixel, sample) stream in counter mode (no reference counterpart).
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+__host__ __device__ __forceinline__ uint32_t counter_seed(uint32_t pixel, uint32_t sample, uint32_t seed) {
+    uint32_t h = fmix32(pixel ^ 0x9E3779B9u);
+    h = fmix32(h ^ (sample * 0x85EBCA6Bu + 0x7F4A7C15u));
+    h = fmix32(h ^ seed);
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scene view passed by value to every kernel
+// ---------------------------------------------------------------------------------------------
+struct DevMaterial {
+    float4 a;  // color.xyz, bits(type)
+    float4 b;  // emission.xyz, ior
+};
+
+struct DevScene {
+    const float4 *nodes;      // 4 x float4 per node
+    const float4 *tris;       // 4 x float4 per triangle, leaf order
+    const uint32_t *lights;   // leaf-order positions of the emissive triangles
+    const DevMaterial *mats;
+    unsigned long long *counters;  // [0] segments [1] nodes [2] tri tests [3] light tests
+    uint32_t nlights;
+    float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];
+    float tan_x, tan_y;
+};
+
+struct TraceStats {
+    uint32_t nodes, tris;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Ray / triangle: uvt = inverse(mat3(AB, AC, -d)) * (o - A) evaluated exactly as glm does
+// (Triangle::intersectPrimitive, main.cpp:478-498).  N = cross(AB, AC) is stored with the
+// triangle; its components are bit-identical to the three cofactors of the inverse's last row.
+// Returns true and the distance when  !(u < 0 || v < 0 || t < 0 || u + v > 1).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool tri_test(float4 q0, float4 q1, float4 q2, v3 o, v3 d, float &tOut) {
+    const float m00 = q0.w, m01 = q1.x, m02 = q1.y;     // AB
+    const float m10 = q1.z, m11 = q1.w, m12 = q2.x;     // AC
+    const float m20 = -d.x, m21 = -d.y, m22 = -d.z;     // -d
+    const float wx = o.x - q0.x, wy = o.y - q0.y, wz = o.z - q0.z;
+    const float ca = m11 * m22 - m21 * m12;
+    const float cb = m01 * m22 - m21 * m02;
+    const float cc = q2.y;  // m01*m12 - m11*m02
+    const float ood = 1.f / ((m00 * ca - m10 * cb) + m20 * cc);
+    const float i00 = ca * ood;
+    const float i10 = -(m10 * m22 - m20 * m12) * ood;
+    const float i20 = (m10 * m21 - m20 * m11) * ood;
+    const float i01 = -cb * ood;
+    const float i11 = (m00 * m22 - m20 * m02) * ood;
+    const float i21 = -(m00 * m21 - m20 * m01) * ood;
+    const float i02 = cc * ood;
+    const float i12 = q2.z * ood;  // -(m00*m12 - m10*m02)
+    const float i22 = q2.w * ood;  // m00*m11 - m10*m01
+    const float u = (i00 * wx + i10 * wy) + i20 * wz;
+    const float v = (i01 * wx + i11 * wy) + i21 * wz;
+    const float t = (i02 * wx + i12 * wy) + i22 * wz;
+    tOut = t;
+    return !(u < 0.f || v < 0.f || t < 0.f || u + v > 1.f);
+}
+
+// Conservative slab test against a padded box; NaNs from 0 * inf drop out of min/max, which
+// leaves that slab unconstrained (never a false miss).
+__device__ __forceinline__ bool box_test(float lox, float loy, float loz, float hix, float hiy, float hiz, v3 o,
+                                         v3 id, float tBest, float &tNear) {
+    const float ax = (lox - o.x) * id.x, bx = (hix - o.x) * id.x;
+    const float ay = (loy - o.y) * id.y, by = (hiy - o.y) * id.y;
+    const float az = (loz - o.z) * id.z, bz = (hiz - o.z) * id.z;
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
+                                     __builtin_fminf(az, bz));
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
+                                     __builtin_fmaxf(az, bz));
+    tNear = tn;
+    return (tn <= tf * 1.0000004f) & (tf >= 0.f) & (tn < tBest);
+}
+
+// Closest hit (BVH::intersect, main.cpp:560-605): the minimum-t triangle among all triangles the
+// ray hits.  `stack` points at this lane's column of an LDS array laid out [kStack][kBlock].
+// triBest = leaf-order triangle position, or -1.  A hit needs t < INF (1e4): the reference
+// prunes every subtree at that distance until a first hit is found.
+template <bool COUNT>
+__device__ __forceinline__ void closest_hit(const DevScene &S, v3 o, v3 d, int *stack, float &tBest, int &triBest,
+                                            TraceStats &st) {
+    const v3 id = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    tBest = kInf;
+    triBest = -1;
+    int sp = 0;
+    int cur = 0;
+    for (;;) {
+        const float4 *np = S.nodes + 4 * (size_t)cur;
+        const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+        if (COUNT) ++st.nodes;
+        float tnL, tnR;
+        bool hL = box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, o, id, tBest, tnL);
+        bool hR = box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, o, id, tBest, tnR);
+        const int cl = __float_as_int(n3.x), cr = __float_as_int(n3.y);
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const bool h = side ? hR : hL;
+            const int c = side ? cr : cl;
+            const float tn = side ? tnR : tnL;
+            if (h && c < 0 && tn < tBest) {
+                const uint32_t ref = ~(uint32_t)c;
+                const uint32_t first = ref >> 3, cnt = (ref & 7u) + 1u;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const float4 *tp = S.tris + 4 * (size_t)(first + k);
+                    float t;
+                    if (COUNT) ++st.tris;
+                    if (tri_test(tp[0], tp[1], tp[2], o, d, t) && t < tBest) {
+                        tBest = t;
+                        triBest = (int)(first + k);
+                    }
+                }
+            }
+        }
+        hL = hL && cl >= 0 && tnL < tBest;
+        hR = hR && cr >= 0 && tnR < tBest;
+        if (hL && hR) {
+            const bool leftFirst = tnL <= tnR;
+            stack[sp * kBlock] = leftFirst ? cr : cl;
+            ++sp;
+            cur = leftFirst ? cl : cr;
+        } else if (hL) {
+            cur = cl;
+        } else if (hR) {
+            cur = cr;
+        } else {
+            if (sp == 0) break;
+            --sp;
+            cur = stack[sp * kBlock];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Camera: generateSample's ray (main.cpp:1212-1215); consumes two uniforms.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ v3 primary_direction(const DevScene &S, uint32_t px, uint32_t py, uint32_t W, uint32_t H,
+                                                uint32_t &rng) {
+    const float u1 = rng_uniform(rng);
+    const float x = (2.f * ((float)px + u1) / (float)W - 1.f) * S.tan_x;
+    const float u2 = rng_uniform(rng);
+    const float y = -(2.f * ((float)py + u2) / (float)H - 1.f) * S.tan_y;
+    const v3 right = mk(S.cam_right[0], S.cam_right[1], S.cam_right[2]);
+    const v3 up = mk(S.cam_up[0], S.cam_up[1], S.cam_up[2]);
+    const v3 fwd = mk(S.cam_fwd[0], S.cam_fwd[1], S.cam_fwd[2]);
+    return normalize(x * right + y * up + fwd);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One path vertex of the reference estimator, in forward (throughput) form.
+// The reference recurses: L = k * L_next + emission (applyLight*, main.cpp:1128-1210); every hit
+// spawns exactly one continuation ray, so the recursion is the chain
+//   L = sum_i T_i * emission_i,  T_{i+1} = T_i * k_i
+// (same estimator and random numbers; only the rounding of the products differs).
+// ---------------------------------------------------------------------------------------------
+struct PathState {
+    v3 o, d;      // current ray
+    v3 T;         // throughput
+    v3 L;         // radiance gathered so far by this sample
+    uint32_t rng; // engine state
+    uint32_t depth;  // rayDepth the next hit is shaded with (main.cpp:1188-1199)
+};
+
+// LightSurface::pdf (main.cpp:771-783): sum over all lights except the surface's own triangle
+// of Triangle::pdf (main.cpp:510-517), no occlusion test, divided by the light count.
+__device__ __forceinline__ float light_pdf(const DevScene &S, v3 x, v3 w, int self, uint32_t &tests) {
+    float ps = 0.f;
+    for (uint32_t k = 0; k < S.nlights; ++k) {
+        const int lt = (int)S.lights[k];
+        if (lt == self) continue;
+        ++tests;
+        const float4 *tp = S.tris + 4 * (size_t)lt;
+        const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
+        float t;
+        if (tri_test(q0, q1, q2, x, w, t)) {
+            v3 n = normalize(mk(q2.y, q2.z, q2.w));
+            if (dot(n, w) > 0.f) n = n * -1.f;
+            const v3 ip = x + t * w;
+            const v3 r = ip - x;
+            ps += q3.z * dot(r, r) / __builtin_fabsf(dot(normalize(r), n));
+        }
+    }
+    if (ps < kEps || __builtin_isnan(ps) || __builtin_isinf(ps)) return 0.f;
+    return ps / (float)S.nlights;
+}
+
+// Shades the hit (t, tri) of ray (P.o, P.d).  Returns true when the path continues with the new
+// ray in P.o / P.d.
+__device__ __forceinline__ bool shade_hit(const DevScene &S, PathState &P, float t, int tri, uint32_t &lightTests) {
+    if (tri < 0) return false;        // miss: backgroundColor is always (0,0,0), main.cpp:694, 1190
+    if (P.depth == 0) return false;   // main.cpp:1195
+    const float4 *tp = S.tris + 4 * (size_t)tri;
+    const float4 q2 = tp[2], q3 = tp[3];
+    const DevMaterial M = S.mats[__float_as_uint(q3.y)];
+    const v3 color = mk(M.a.x, M.a.y, M.a.z);
+    const v3 emission = mk(M.b.x, M.b.y, M.b.z);
+    const int type = __float_as_int(M.a.w);
+    P.L = P.L + P.T * emission;       // every branch of applyLight* adds the emission
+    if (P.depth == 1) return false;   // main.cpp:1197
+
+    // Intersection::update (main.cpp:84-95) for the winning triangle
+    v3 n = normalize(mk(q2.y, q2.z, q2.w));
+    const bool inside = dot(n, P.d) > 0.f;
+    if (inside) n = n * -1.f;
+    const float nl = -dot(n, P.d);
+    const v3 p = P.o + t * P.d;
+    const v3 nEps = n * kEps;
+    const v3 pPlus = p + nEps;
+    const v3 pMinus = p - nEps;
+
+    if (type == 0) {  // applyLightDiffuser, main.cpp:1128-1141, Mix 793-804
+        v3 w;
+        if (rng_uniform(P.rng) < 0.5f) {  // Cosine::sample, main.cpp:739-746
+            const float gx = rng_normal(P.rng);
+            const float gy = rng_normal(P.rng);
+            const float gz = rng_normal(P.rng);
+            w = normalize(normalize(mk(gx, gy, gz)) + n * (1.f + kEps));
+        } else if (S.nlights == 0) {      // LightSurface::sample, main.cpp:764-769
+            w = mk(0.f, 0.f, 0.f);
+        } else {
+            const uint32_t k = rng_uint(P.rng, S.nlights);
+            const float4 *lp = S.tris + 4 * (size_t)S.lights[k];
+            const float4 l0 = lp[0], l1 = lp[1], l2 = lp[2];
+            float u = rng_uniform(P.rng);  // Triangle::samplePoint, main.cpp:500-508
+            float v = rng_uniform(P.rng);
+            if (u + v > 1.f) {
+                u = 1.f - u;
+                v = 1.f - v;
+            }
+            const v3 pt = mk(l0.x, l0.y, l0.z) + u * mk(l0.w, l1.x, l1.y) + v * mk(l1.z, l1.w, l2.x);
+            w = normalize(pt - pPlus);
+        }
+        const float dn = dot(w, n);  // Cosine::pdf, main.cpp:748-754
+        const float pc = (dn < kEps) ? 0.f : dn * kOneOverPi;
+        const float pdf = 0.5f * pc + 0.5f * light_pdf(S, pPlus, w, tri, lightTests);
+        const float wn = dot(w, n);
+        if (wn < 0.f || pdf < kEps) return false;
+        P.T = P.T * mk(color.x * kOneOverPi * wn / pdf, color.y * kOneOverPi * wn / pdf, color.z * kOneOverPi * wn / pdf);
+        P.o = pPlus;
+        P.d = w;
+    } else if (type == 1) {  // applyLightMetallic + getReflectedLight, main.cpp:1120-1126, 1143-1147
+        P.T = P.T * color;
+        P.o = pPlus;
+        P.d = normalize(P.d + 2.f * n * nl);
+    } else {  // applyLightDielectric, main.cpp:1149-1186
+        float n1 = 1.f, n2 = M.b.w;
+        if (inside) {
+            n1 = n2;
+            n2 = 1.f;
+        }
+        const float n12 = n1 / n2;
+        const float sn = n12 * __builtin_sqrtf(1.f - nl * nl);
+        bool reflect = sn > 1.f;
+        if (!reflect) {
+            float r0 = (n1 - n2) / (n1 + n2);
+            r0 *= r0;
+            const float mnl = 1.f - nl;
+            const float mnlsq = mnl * mnl;
+            const float r = r0 + (1.f - r0) * mnlsq * mnlsq * mnl;
+            reflect = rng_uniform(P.rng) < r;
+        }
+        if (reflect) {
+            P.o = pPlus;
+            P.d = normalize(P.d + 2.f * n * nl);
+        } else {
+            const v3 rd = n12 * P.d + (n12 * nl - __builtin_sqrtf(1.f - sn * sn)) * n;
+            P.d = normalize(rd);
+            P.o = pMinus;
+            if (!inside) P.T = P.T * color;
+        }
+    }
+    --P.depth;
+    return true;
+}
+
+// ACES + gamma of generatePixel (main.cpp:1226-1231, 827-838) for one channel.
+__device__ __forceinline__ float tonemap_channel(float sum, float spp) {
+    const float x = sum / spp;
+    float r = (x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f);
+    r = __builtin_fminf(__builtin_fmaxf(r, 0.f), 1.f);
+    return __builtin_powf(r, 1.f / 2.2f);
+}
+
+}  // namespace rtd

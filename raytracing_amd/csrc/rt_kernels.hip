@@ -1,0 +1,362 @@
+// rt_kernels.hip -- gfx950 kernels of the path tracer and their launchers.
+//
+// Kernels (all 256-thread workgroups = 4 wave64s, per-lane traversal stack in LDS):
+//   k_intersect      closest hit for a caller-supplied ray batch      (intersectScene, main.cpp:1113)
+//   k_primary        camera ray of sample 0 per pixel + closest hit   (main.cpp:1212-1216, 1221)
+//   k_render_mega    persistent lane per pixel, path regeneration     (generatePixel's loop, main.cpp:1220-1225)
+//   wf_generate / wf_extend / wf_shade / wf_accumulate
+//                    the same estimator as queue-per-bounce kernels over SoA path records
+//   k_tonemap        mean, ACES, gamma, byte conversion               (main.cpp:1226-1231, 840-846)
+//
+// Pixel kernels map a wave to an 8x8 pixel tile (coherent primary rays) and a workgroup to a
+// 16x16 tile; workgroup ids are re-dealt so that the workgroups of one XCD cover a contiguous
+// band of the image and its L2 keeps the part of the BVH that band looks at.
+#include "rt_launch.h"
+
+using namespace rtd;
+
+namespace {
+
+// blockIdx.x -> logical tile index; workgroups b and b+8 share an XCD (round-robin dispatch), so
+// XCD k is given the k-th contiguous slice of the tile list.  Bijective for any block count.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nblocks) {
+    const uint32_t xcd = b & 7u, j = b >> 3;
+    const uint32_t q = nblocks >> 3, r = nblocks & 7u;
+    const uint32_t base = (xcd < r) ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + j;
+}
+
+// Pixel of this lane: 16x16 tile per workgroup, 8x8 sub-tile per wave.
+__device__ __forceinline__ bool tile_pixel(uint32_t W, uint32_t H, uint32_t &px, uint32_t &py) {
+    const uint32_t tilesX = (W + 15u) >> 4;
+    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t tx = tile % tilesX, ty = tile / tilesX;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    px = (tx << 4) + ((wave & 1u) << 3) + (lane & 7u);
+    py = (ty << 4) + ((wave >> 1) << 3) + (lane >> 3);
+    return px < W && py < H;
+}
+
+__device__ __forceinline__ void add_counters(const DevScene &S, uint32_t segs, const TraceStats &st, uint32_t lights,
+                                             bool count) {
+    atomicAdd(&S.counters[0], (unsigned long long)segs);
+    if (count) {
+        atomicAdd(&S.counters[1], (unsigned long long)st.nodes);
+        atomicAdd(&S.counters[2], (unsigned long long)st.tris);
+    }
+    atomicAdd(&S.counters[3], (unsigned long long)lights);
+}
+
+__device__ __forceinline__ uint32_t tri_loader_id(const DevScene &S, int tri) {
+    return __float_as_uint(S.tris[4 * (size_t)tri + 3].x);
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, uint64_t n, const float *__restrict__ o,
+                                                       const float *__restrict__ d, uint32_t *__restrict__ prim_id,
+                                                       float *__restrict__ tout) {
+    __shared__ int s_stack[kStack * kBlock];
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const v3 ro = mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
+    const v3 rd = mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    float t;
+    int tri;
+    TraceStats st{0, 0};
+    closest_hit<COUNT>(S, ro, rd, s_stack + threadIdx.x, t, tri, st);
+    prim_id[i] = tri >= 0 ? tri_loader_id(S, tri) : 0xFFFFFFFFu;
+    tout[i] = t;
+    add_counters(S, 1u, st, 0u, COUNT);
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_primary(DevScene S, uint32_t W, uint32_t H, uint32_t *__restrict__ prim_id,
+                                                     float *__restrict__ tout) {
+    __shared__ int s_stack[kStack * kBlock];
+    uint32_t px, py;
+    if (!tile_pixel(W, H, px, py)) return;
+    const uint32_t pix = py * W + px;
+    uint32_t rng = rng_seed(pix);  // minstd_rand{py * W + px}, main.cpp:1221
+    const v3 rd = primary_direction(S, px, py, W, H, rng);
+    const v3 ro = mk(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]);
+    float t;
+    int tri;
+    TraceStats st{0, 0};
+    closest_hit<COUNT>(S, ro, rd, s_stack + threadIdx.x, t, tri, st);
+    prim_id[pix] = tri >= 0 ? tri_loader_id(S, tri) : 0xFFFFFFFFu;
+    tout[pix] = t;
+    add_counters(S, 1u, st, 0u, COUNT);
+}
+
+// One lane owns one pixel and runs its samples back to back; when a path ends the lane starts
+// the next sample in the same loop iteration ("path regeneration"), so lanes of a wave stay
+// busy although their paths have different lengths.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_render_mega(DevScene S, rt::RenderParams rp, float *__restrict__ sum) {
+    __shared__ int s_stack[kStack * kBlock];
+    uint32_t px, py;
+    if (!tile_pixel(rp.W, rp.H, px, py)) return;
+    const uint32_t pix = py * rp.W + px;
+    const v3 camPos = mk(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]);
+
+    PathState P;
+    P.rng = rng_seed(pix);  // reference stream; overwritten per sample in counter mode
+    P.o = camPos;
+    P.d = mk(0.f, 0.f, -1.f);
+    P.T = mk(1.f, 1.f, 1.f);
+    P.L = mk(0.f, 0.f, 0.f);
+    P.depth = 0;
+    v3 acc = mk(0.f, 0.f, 0.f);
+    uint32_t s = 0, segs = 0, lightTests = 0;
+    bool active = false;
+    TraceStats st{0, 0};
+    for (;;) {
+        if (!active) {
+            if (s >= rp.spp_count) break;
+            if (rp.rng_mode == 1) P.rng = rng_seed(counter_seed(pix, rp.spp_begin + s, rp.seed));
+            P.d = primary_direction(S, px, py, rp.W, rp.H, P.rng);
+            P.o = camPos;
+            P.T = mk(1.f, 1.f, 1.f);
+            P.L = mk(0.f, 0.f, 0.f);
+            P.depth = rp.max_depth;
+            active = true;
+            ++s;
+        }
+        float t;
+        int tri;
+        closest_hit<COUNT>(S, P.o, P.d, s_stack + threadIdx.x, t, tri, st);
+        ++segs;
+        active = shade_hit(S, P, t, tri, lightTests);
+        if (!active) acc = acc + P.L;  // color += generateSample(...), main.cpp:1224
+    }
+    sum[3 * (size_t)pix] = acc.x;
+    sum[3 * (size_t)pix + 1] = acc.y;
+    sum[3 * (size_t)pix + 2] = acc.z;
+    add_counters(S, segs, st, lightTests, COUNT);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wavefront pipeline.  Path record i lives at slot i of every SoA array for its whole life;
+// queues hold the slot indices still alive.  Slot i renders pixel i % npix, sample
+// spp0 + i / npix.
+// ---------------------------------------------------------------------------------------------
+struct WfView {
+    float *ray, *thr, *rad;
+    uint32_t *rng, *meta;
+    float *hit_t;
+    int32_t *hit_tri;
+    uint32_t cap;
+};
+
+__global__ __launch_bounds__(kBlock) void wf_generate(DevScene S, rt::RenderParams rp, WfView V, uint32_t npaths,
+                                                       uint32_t spp0, uint32_t *__restrict__ qcount) {
+    const uint32_t npix = rp.W * rp.H;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npaths; i += gridDim.x * kBlock) {
+        const uint32_t pix = i % npix, sample = spp0 + i / npix;
+        const uint32_t px = pix % rp.W, py = pix / rp.W;
+        uint32_t rng = rng_seed(counter_seed(pix, sample, rp.seed));
+        const v3 d = primary_direction(S, px, py, rp.W, rp.H, rng);
+        V.ray[i] = S.cam_pos[0];
+        V.ray[V.cap + i] = S.cam_pos[1];
+        V.ray[2 * (size_t)V.cap + i] = S.cam_pos[2];
+        V.ray[3 * (size_t)V.cap + i] = d.x;
+        V.ray[4 * (size_t)V.cap + i] = d.y;
+        V.ray[5 * (size_t)V.cap + i] = d.z;
+        V.thr[i] = 1.f;
+        V.thr[V.cap + i] = 1.f;
+        V.thr[2 * (size_t)V.cap + i] = 1.f;
+        V.rad[i] = 0.f;
+        V.rad[V.cap + i] = 0.f;
+        V.rad[2 * (size_t)V.cap + i] = 0.f;
+        V.rng[i] = rng;
+        V.meta[i] = rp.max_depth;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        qcount[0] = npaths;
+        qcount[1] = 0u;
+    }
+}
+
+// Traces the rays of the input queue (null queue = identity: slots 0..count-1) and stores the hit.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const uint32_t *__restrict__ queue,
+                                                     const uint32_t *__restrict__ qcount_in,
+                                                     uint32_t *__restrict__ qcount_zero) {
+    __shared__ int s_stack[kStack * kBlock];
+    const uint32_t count = *qcount_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *qcount_zero = 0u;  // the queue the next shade pass fills
+    uint32_t segs = 0;
+    TraceStats st{0, 0};
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < count; j += gridDim.x * kBlock) {
+        const uint32_t i = queue ? queue[j] : j;
+        const v3 o = mk(V.ray[i], V.ray[V.cap + i], V.ray[2 * (size_t)V.cap + i]);
+        const v3 d = mk(V.ray[3 * (size_t)V.cap + i], V.ray[4 * (size_t)V.cap + i], V.ray[5 * (size_t)V.cap + i]);
+        float t;
+        int tri;
+        closest_hit<COUNT>(S, o, d, s_stack + threadIdx.x, t, tri, st);
+        V.hit_t[i] = t;
+        V.hit_tri[i] = tri;
+        ++segs;
+    }
+    if (segs) add_counters(S, segs, st, 0u, COUNT);
+}
+
+// Shades the hits of the input queue and appends the surviving paths to the output queue:
+// one ballot per wave, one atomic per wave, lanes write at their prefix offset.
+__global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const uint32_t *__restrict__ queue,
+                                                    const uint32_t *__restrict__ qcount_in,
+                                                    uint32_t *__restrict__ queue_out, uint32_t *__restrict__ qcount_out) {
+    const uint32_t count = *qcount_in;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t lightTests = 0;
+    // every lane of a wave runs the same number of iterations so the ballot sees the whole wave
+    const uint32_t stride = gridDim.x * kBlock;
+    const uint32_t rounds = (count + stride - 1u) / stride;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t j = r * stride + blockIdx.x * kBlock + threadIdx.x;
+        bool alive = false;
+        uint32_t i = 0;
+        if (j < count) {
+            i = queue ? queue[j] : j;
+            PathState P;
+            P.o = mk(V.ray[i], V.ray[V.cap + i], V.ray[2 * (size_t)V.cap + i]);
+            P.d = mk(V.ray[3 * (size_t)V.cap + i], V.ray[4 * (size_t)V.cap + i], V.ray[5 * (size_t)V.cap + i]);
+            P.T = mk(V.thr[i], V.thr[V.cap + i], V.thr[2 * (size_t)V.cap + i]);
+            P.L = mk(V.rad[i], V.rad[V.cap + i], V.rad[2 * (size_t)V.cap + i]);
+            P.rng = V.rng[i];
+            P.depth = V.meta[i];
+            alive = shade_hit(S, P, V.hit_t[i], V.hit_tri[i], lightTests);
+            V.rad[i] = P.L.x;
+            V.rad[V.cap + i] = P.L.y;
+            V.rad[2 * (size_t)V.cap + i] = P.L.z;
+            if (alive) {
+                V.ray[i] = P.o.x;
+                V.ray[V.cap + i] = P.o.y;
+                V.ray[2 * (size_t)V.cap + i] = P.o.z;
+                V.ray[3 * (size_t)V.cap + i] = P.d.x;
+                V.ray[4 * (size_t)V.cap + i] = P.d.y;
+                V.ray[5 * (size_t)V.cap + i] = P.d.z;
+                V.thr[i] = P.T.x;
+                V.thr[V.cap + i] = P.T.y;
+                V.thr[2 * (size_t)V.cap + i] = P.T.z;
+                V.rng[i] = P.rng;
+                V.meta[i] = P.depth;
+            }
+        }
+        const unsigned long long mask = __ballot(alive);
+        if (mask) {
+            uint32_t base = 0;
+            if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(qcount_out, (uint32_t)__builtin_popcountll(mask));
+            base = __shfl(base, __builtin_ctzll(mask));
+            if (alive) queue_out[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = i;
+        }
+    }
+    if (lightTests) atomicAdd(&S.counters[3], (unsigned long long)lightTests);
+}
+
+// radiance_sum[pix] (+)= sum over the batch's sample slots, in slot order (deterministic).
+__global__ __launch_bounds__(kBlock) void wf_accumulate(WfView V, uint32_t npix, uint32_t nslots, int first,
+                                                         float *__restrict__ sum) {
+    for (uint32_t pix = blockIdx.x * kBlock + threadIdx.x; pix < npix; pix += gridDim.x * kBlock) {
+        v3 acc = first ? mk(0.f, 0.f, 0.f) : mk(sum[3 * (size_t)pix], sum[3 * (size_t)pix + 1], sum[3 * (size_t)pix + 2]);
+        for (uint32_t s = 0; s < nslots; ++s) {
+            const size_t i = (size_t)s * npix + pix;
+            acc = acc + mk(V.rad[i], V.rad[V.cap + i], V.rad[2 * (size_t)V.cap + i]);
+        }
+        sum[3 * (size_t)pix] = acc.x;
+        sum[3 * (size_t)pix + 1] = acc.y;
+        sum[3 * (size_t)pix + 2] = acc.z;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_tonemap(const float *__restrict__ sum, uint64_t n3, float spp,
+                                                     float *__restrict__ out_float, uint8_t *__restrict__ out_rgb) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n3; i += (uint64_t)gridDim.x * kBlock) {
+        const float c = tonemap_channel(sum[i], spp);
+        if (out_float) out_float[i] = c;
+        if (out_rgb) out_rgb[i] = (uint8_t)(c * 255.f);  // truncation, colorFloatToInt main.cpp:840-846
+    }
+}
+
+inline uint32_t pixel_grid(uint32_t W, uint32_t H) { return ((W + 15u) / 16u) * ((H + 15u) / 16u); }
+constexpr uint32_t kPersistentBlocks = 256u * 8u;  // 256 CUs x 8 workgroups for grid-stride kernels
+
+}  // namespace
+
+namespace rt {
+
+hipError_t launch_intersect(const DevScene &S, uint64_t n, const float *o, const float *d, uint32_t *prim_id, float *t,
+                            bool count, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint32_t grid = (uint32_t)((n + kBlock - 1) / kBlock);
+    if (count) hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(kBlock), 0, stream, S, n, o, d, prim_id, t);
+    else hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(kBlock), 0, stream, S, n, o, d, prim_id, t);
+    return hipGetLastError();
+}
+
+hipError_t launch_primary(const DevScene &S, uint32_t W, uint32_t H, uint32_t *prim_id, float *t, bool count,
+                          hipStream_t stream) {
+    const uint32_t grid = pixel_grid(W, H);
+    if (count) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), 0, stream, S, W, H, prim_id, t);
+    else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), 0, stream, S, W, H, prim_id, t);
+    return hipGetLastError();
+}
+
+hipError_t launch_render_mega(const DevScene &S, const RenderParams &rp, float *radiance_sum, bool count,
+                              hipStream_t stream) {
+    const uint32_t grid = pixel_grid(rp.W, rp.H);
+    if (count) hipLaunchKernelGGL(k_render_mega<true>, dim3(grid), dim3(kBlock), 0, stream, S, rp, radiance_sum);
+    else hipLaunchKernelGGL(k_render_mega<false>, dim3(grid), dim3(kBlock), 0, stream, S, rp, radiance_sum);
+    return hipGetLastError();
+}
+
+hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, float *radiance_sum,
+                                   const WavefrontBuffers &wb, bool count, hipStream_t stream) {
+    const uint32_t npix = rp.W * rp.H;
+    const uint32_t slots = wb.capacity / npix;  // samples in flight per pass (host guarantees >= 1)
+    WfView V{wb.ray, wb.thr, wb.rad, wb.rng, wb.meta, wb.hit_t, wb.hit_tri, wb.capacity};
+    uint32_t done = 0;
+    bool first = true;
+    while (done < rp.spp_count) {
+        const uint32_t ns = (rp.spp_count - done < slots) ? rp.spp_count - done : slots;
+        const uint32_t npaths = ns * npix;
+        const uint32_t grid = (npaths + kBlock - 1) / kBlock < kPersistentBlocks ? (npaths + kBlock - 1) / kBlock
+                                                                                 : kPersistentBlocks;
+        hipLaunchKernelGGL(wf_generate, dim3(grid), dim3(kBlock), 0, stream, S, rp, V, npaths, rp.spp_begin + done,
+                           wb.qcount);
+        for (uint32_t b = 0; b < rp.max_depth; ++b) {
+            const uint32_t in = b & 1u, out = in ^ 1u;
+            const uint32_t *qin = (b == 0) ? nullptr : wb.queue[in];
+            if (count)
+                hipLaunchKernelGGL(wf_extend<true>, dim3(grid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in,
+                                   wb.qcount + out);
+            else
+                hipLaunchKernelGGL(wf_extend<false>, dim3(grid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in,
+                                   wb.qcount + out);
+            hipLaunchKernelGGL(wf_shade, dim3(grid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in, wb.queue[out],
+                               wb.qcount + out);
+        }
+        const uint32_t agrid = (npix + kBlock - 1) / kBlock < kPersistentBlocks ? (npix + kBlock - 1) / kBlock
+                                                                                : kPersistentBlocks;
+        hipLaunchKernelGGL(wf_accumulate, dim3(agrid), dim3(kBlock), 0, stream, V, npix, ns, first ? 1 : 0, radiance_sum);
+        first = false;
+        done += ns;
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (rp.spp_count == 0) return hipMemsetAsync(radiance_sum, 0, (size_t)npix * 3 * sizeof(float), stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_tonemap(const float *radiance_sum, uint64_t npixels, uint32_t spp, float *out_float, uint8_t *out_rgb,
+                          hipStream_t stream) {
+    const uint64_t n3 = npixels * 3;
+    if (n3 == 0) return hipSuccess;
+    uint64_t grid = (n3 + kBlock - 1) / kBlock;
+    if (grid > kPersistentBlocks) grid = kPersistentBlocks;
+    hipLaunchKernelGGL(k_tonemap, dim3((uint32_t)grid), dim3(kBlock), 0, stream, radiance_sum, n3, (float)spp, out_float,
+                       out_rgb);
+    return hipGetLastError();
+}
+
+}  // namespace rt

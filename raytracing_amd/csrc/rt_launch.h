@@ -1,0 +1,45 @@
+// rt_launch.h -- host-callable launchers of the gfx950 kernels (defined in rt_kernels.hip).
+// All launchers enqueue on `stream` and return the launch status; none synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_device.h"
+
+namespace rt {
+
+struct RenderParams {
+    uint32_t W, H;
+    uint32_t spp_begin, spp_count;
+    uint32_t max_depth;
+    int rng_mode;
+    uint32_t seed;
+};
+
+// Scratch of the wavefront pipeline: SoA path records for `capacity` paths, two index queues,
+// queue counters.  Owned by the scene, sized on first use.
+struct WavefrontBuffers {
+    uint32_t capacity = 0;
+    float *ray = nullptr;       // 6 x capacity: ox, oy, oz, dx, dy, dz (one array per component)
+    float *thr = nullptr;       // 3 x capacity: throughput
+    float *rad = nullptr;       // 3 x capacity: radiance gathered by the sample in flight
+    uint32_t *rng = nullptr;    // capacity: engine state
+    uint32_t *meta = nullptr;   // capacity: depth left
+    float *hit_t = nullptr;     // capacity
+    int32_t *hit_tri = nullptr; // capacity
+    uint32_t *queue[2] = {nullptr, nullptr};  // path indices alive in the current / next bounce
+    uint32_t *qcount = nullptr; // [0], [1]: queue lengths (device), [2..]: spare
+};
+
+hipError_t launch_intersect(const rtd::DevScene &S, uint64_t n, const float *o, const float *d, uint32_t *prim_id,
+                            float *t, bool count, hipStream_t stream);
+hipError_t launch_primary(const rtd::DevScene &S, uint32_t W, uint32_t H, uint32_t *prim_id, float *t, bool count,
+                          hipStream_t stream);
+hipError_t launch_render_mega(const rtd::DevScene &S, const RenderParams &rp, float *radiance_sum, bool count,
+                              hipStream_t stream);
+hipError_t launch_render_wavefront(const rtd::DevScene &S, const RenderParams &rp, float *radiance_sum,
+                                   const WavefrontBuffers &wb, bool count, hipStream_t stream);
+hipError_t launch_tonemap(const float *radiance_sum, uint64_t npixels, uint32_t spp, float *out_float,
+                          uint8_t *out_rgb, hipStream_t stream);
+
+}  // namespace rt
