@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the path-tracing hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--pipeline mega|wavefront]
+
+Workload (default `spheres1m`): the million-triangle mixed-material scene at 1920x1080, path depth 8,
+counter RNG, 128 samples per pixel PER GPU (8 GPUs = the 1024-spp frame BASELINE.json's metric is
+quoted on; weak scaling).  One step = every rank renders its sample range of the whole frame into its
+radiance-sum buffer, the buffers are summed onto rank 0 (RCCL reduce; nothing for N=1) and rank 0 tone-maps
+the frame.  The scene is resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+For N>1 launch with torch.distributed.run (one process per GPU); RANK/LOCAL_RANK/WORLD_SIZE come from
+the environment.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+WORKLOADS = {
+    # name: (scene generator name, generator kwargs, W, H, spp per GPU, depth)
+    "spheres1m": ("spheres1m", {}, 1920, 1080, 128, 8),
+    "cornell": ("cornell", {}, 1920, 1080, 256, 8),
+    "glass4k": ("glass", {"grid": 6, "subdiv": 5}, 3840, 2160, 64, 16),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="spheres1m", choices=sorted(WORKLOADS))
+    ap.add_argument("--pipeline", default="mega", choices=["mega", "wavefront"])
+    ap.add_argument("--spp-per-gpu", type=int, default=0, help="override the workload's samples per pixel per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-primary", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import raytracing_amd as rt
+    from raytracing_amd import scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus (%d) does not match WORLD_SIZE (%d)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    gen, gen_kw, W, H, spp_gpu, depth = WORKLOADS[args.workload]
+    if args.spp_per_gpu > 0:
+        spp_gpu = args.spp_per_gpu
+    pipeline = rt.PIPE_MEGAKERNEL if args.pipeline == "mega" else rt.PIPE_WAVEFRONT
+    seed = 0x5EED
+    npix = W * H
+
+    tmp = tempfile.mkdtemp(prefix="rt_bench_%d_" % rank)
+    path = scenes.generate(gen, os.path.join(tmp, gen + ".gltf"), **gen_kw)
+    host = rt.load_gltf(path, W, H)
+    scene = rt.Scene(host, device=local_rank)
+    stats = scene.stats()
+
+    stream = torch.cuda.current_stream()
+    buf = torch.empty(npix * 3, dtype=torch.float32, device=dev)
+    rgb = torch.empty(npix * 3, dtype=torch.uint8, device=dev)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(k=None):
+        if k is not None:
+            ev0[k].record(stream)
+        scene.render_dev(W, H, spp_gpu, buf.data_ptr(), max_depth=depth, rng_mode=rt.RNG_COUNTER, seed=seed,
+                         spp_begin=rank * spp_gpu, pipeline=pipeline, stream=stream)
+        if k is not None:
+            ev1[k].record(stream)
+        if world > 1:
+            dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            scene.tonemap_dev(buf.data_ptr(), npix, spp_gpu * world, out_rgb_ptr=rgb.data_ptr(), stream=stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    scene.reset_counters(stream)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    segs = scene.counters()["segments"]
+    kern_ms = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
+    t = torch.tensor([elapsed, float(segs)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, total_segs = float(tmax[0]), float(tsum[1])
+    else:
+        total_segs = float(segs)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (this rank's render launch) ----------------------------
+    # Algorithmic bytes per ray segment: 64 B per BVH node visited (both child boxes), 48 B per
+    # ray/triangle test, 32 B for the winning triangle's shading record, 64 B per light-pdf triangle
+    # test; per pixel 12 B of output.  Visit counts come from the counting build of the same kernel
+    # on the same workload (one extra launch, outside the timed region).
+    scene.set_counting(True)
+    scene.reset_counters(stream)
+    count_spp = min(spp_gpu, 4)
+    scene.render_dev(W, H, count_spp, buf.data_ptr(), max_depth=depth, rng_mode=rt.RNG_COUNTER, seed=seed,
+                     spp_begin=0, pipeline=pipeline, stream=stream)
+    c = scene.counters()
+    scene.set_counting(False)
+    n_node = c["nodes"] / c["segments"]
+    n_tri = c["tri_tests"] / c["segments"]
+    n_light = c["light_tests"] / c["segments"]
+    seg_per_sample = c["segments"] / float(npix * count_spp)
+    state_bytes = 0.0 if pipeline == rt.PIPE_MEGAKERNEL else 2 * (24 + 12 + 12 + 8) + 8 + 8
+    bytes_per_seg = 64.0 * n_node + 48.0 * n_tri + 32.0 + 64.0 * n_light + state_bytes
+    segs_per_launch = segs / float(args.steps)
+    launch_ms = sum(kern_ms) / len(kern_ms)
+    achieved = (segs_per_launch * bytes_per_seg + 12.0 * npix) / (launch_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "kernel": "k_render_mega" if pipeline == rt.PIPE_MEGAKERNEL else "wf_extend+wf_shade",
+                "launch_ms": round(launch_ms, 3), "bytes_per_segment": round(bytes_per_seg, 1),
+                "nodes_per_segment": round(n_node, 2), "tri_tests_per_segment": round(n_tri, 2),
+                "light_tests_per_segment": round(n_light, 2), "segments_per_sample": round(seg_per_sample, 3)}
+
+    # ---- primary-ray closest hit on the 100k-triangle mesh (informational) ----------------------
+    extra = {}
+    if not args.no_primary:
+        p2 = scenes.generate("heightfield100k", os.path.join(tmp, "hf100k.gltf"))
+        s2 = rt.Scene(rt.load_gltf(p2, 1920, 1080), device=local_rank)
+        ids = torch.empty(1920 * 1080, dtype=torch.int32, device=dev)
+        ts = torch.empty(1920 * 1080, dtype=torch.float32, device=dev)
+        for _ in range(3):
+            s2.trace_primary_dev(1920, 1080, ids.data_ptr(), ts.data_ptr(), stream=stream)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        reps = 20
+        for _ in range(reps):
+            s2.trace_primary_dev(1920, 1080, ids.data_ptr(), ts.data_ptr(), stream=stream)
+        b.record(stream)
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
+        extra["primary_100k_tris_1080p"] = {"ms_per_frame": round(ms, 4), "Mrays_per_s": round(1920 * 1080 / ms * 1e-3, 1),
+                                            "ntri": s2.stats()["ntri"]}
+        s2.close()
+
+    # ---- CPU baseline: the oracle (a port of the reference's CPU path) on this host's cores ------
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import oracle
+        cw, ch, cspp = W // 4, H // 4, 4
+        host_small = rt.load_gltf(path, cw, ch).as_dict()
+        tb = time.perf_counter()
+        orc = oracle.OracleScene(host_small["tri_verts"], host_small["tri_material"], host_small["materials"],
+                                 host_small["camera"])
+        build_s = time.perf_counter() - tb
+        tb = time.perf_counter()
+        _, cc = orc.render(cw, ch, cspp, max_depth=depth, rng_mode=1, seed=seed)
+        render_s = time.perf_counter() - tb
+        cpu = {"value": round(cc["segments"] / render_s * 1e-6, 4), "unit": "Mrays/s", "cores": oracle.num_threads(),
+               "kind": "port",
+               "sample": "%dx%d, %d spp of the same scene, depth and RNG (render only; oracle BVH build %.1f s)"
+                         % (cw, ch, cspp, build_s)}
+        orc.close()
+
+    value = total_segs / elapsed * 1e-6
+    out = {
+        "metric": "Mrays/s (all bounces)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %d triangles, %dx%d, %d spp per GPU (%d total), depth %d, counter RNG, %s pipeline"
+                               % (args.workload, stats["ntri"], W, H, spp_gpu, spp_gpu * world, depth, args.pipeline),
+                   "parallelism": "spp-split x%d + RCCL reduce" % world if world > 1 else "single GPU",
+                   "ms_per_frame": round(elapsed / args.steps * 1e3, 3),
+                   "bvh": {"nodes": stats["nnodes"], "height": stats["tree_height"],
+                           "build_s": round(stats["build_seconds"], 3)}},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    out.update(extra)
+    print(json.dumps(out))
+    scene.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -171,61 +171,108 @@ __device__ __forceinline__ bool box_test(float lox, float loy, float loz, float 
 }
 
 // Closest hit (BVH::intersect, main.cpp:560-605): the minimum-t triangle among all triangles the
-// ray hits.  `stack` points at this lane's column of an LDS array laid out [kStack][kBlock].
-// triBest = leaf-order triangle position, or -1.  A hit needs t < INF (1e4): the reference
-// prunes every subtree at that distance until a first hit is found.
+// ray hits.  A hit needs t < INF (1e4): the reference prunes every subtree at that distance until a
+// first hit is found.
+//
+// The traversal is a per-lane state machine in "while-while" form: a node phase that walks inner
+// nodes and only REMEMBERS the leaves it reaches (one postponed in `leaf`, a second one left in
+// `cur`), then a leaf phase in which the lanes of the wave run their ray/triangle tests together.
+// Testing a leaf the moment one lane reaches it would make all 64 lanes step through the
+// triangle code on almost every iteration.  The stack holds inner-node and leaf references alike;
+// it lives in LDS as [kStack][kBlock] so that lane l touches bank l % 32 only.
+constexpr int kSentinel = 0x7FFFFFFF;  // "stack is empty": never a node index, never a leaf reference
+
+template <bool COUNT>
+struct Traversal {
+    v3 o, d, id;
+    float tBest;
+    int triBest;
+    int cur;   // >= 0 inner node to visit, < 0 leaf reference, kSentinel = nothing left
+    int leaf;  // postponed leaf reference (< 0) or 0 = none
+    int sp;
+    int *stack;
+
+    __device__ __forceinline__ void start(v3 ro, v3 rd, int *lane_stack) {
+        o = ro;
+        d = rd;
+        id = mk(1.f / rd.x, 1.f / rd.y, 1.f / rd.z);
+        tBest = kInf;
+        triBest = -1;
+        cur = 0;
+        leaf = 0;
+        sp = 0;
+        stack = lane_stack;
+    }
+    __device__ __forceinline__ void idle() {  // a lane with no ray: steps are no-ops
+        cur = kSentinel;
+        leaf = 0;
+        sp = 0;
+    }
+    __device__ __forceinline__ bool done() const { return cur == kSentinel && leaf == 0; }
+    __device__ __forceinline__ int pop() {
+        if (sp == 0) return kSentinel;
+        --sp;
+        return stack[sp * kBlock];
+    }
+
+    // One round: walk inner nodes until this lane holds a leaf (or has nothing left), then test
+    // the triangles of the leaves it holds.
+    __device__ __forceinline__ void step(const DevScene &S, TraceStats &st) {
+        while (cur >= 0 && cur != kSentinel) {
+            const float4 *np = S.nodes + 4 * (size_t)cur;
+            const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            if (COUNT) ++st.nodes;
+            float tnL, tnR;
+            const bool hL = box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, o, id, tBest, tnL);
+            const bool hR = box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, o, id, tBest, tnR);
+            const int cl = __float_as_int(n3.x), cr = __float_as_int(n3.y);
+            if (hL && hR) {
+                const bool leftFirst = tnL <= tnR;
+                stack[sp * kBlock] = leftFirst ? cr : cl;
+                ++sp;
+                cur = leftFirst ? cl : cr;
+            } else if (hL) {
+                cur = cl;
+            } else if (hR) {
+                cur = cr;
+            } else {
+                cur = pop();
+            }
+            if (cur < 0 && leaf == 0) {  // postpone the first leaf and keep walking
+                leaf = cur;
+                cur = pop();
+            }
+            if (__all(leaf != 0)) break;  // every lane still walking already holds a leaf
+        }
+        while (leaf != 0) {
+            const uint32_t ref = ~(uint32_t)leaf;
+            const uint32_t first = ref >> 3, cnt = (ref & 7u) + 1u;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const float4 *tp = S.tris + 4 * (size_t)(first + k);
+                float t;
+                if (COUNT) ++st.tris;
+                if (tri_test(tp[0], tp[1], tp[2], o, d, t) && t < tBest) {
+                    tBest = t;
+                    triBest = (int)(first + k);
+                }
+            }
+            leaf = 0;
+            if (cur < 0) {
+                leaf = cur;
+                cur = pop();
+            }
+        }
+    }
+};
+
 template <bool COUNT>
 __device__ __forceinline__ void closest_hit(const DevScene &S, v3 o, v3 d, int *stack, float &tBest, int &triBest,
                                             TraceStats &st) {
-    const v3 id = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
-    tBest = kInf;
-    triBest = -1;
-    int sp = 0;
-    int cur = 0;
-    for (;;) {
-        const float4 *np = S.nodes + 4 * (size_t)cur;
-        const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-        if (COUNT) ++st.nodes;
-        float tnL, tnR;
-        bool hL = box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, o, id, tBest, tnL);
-        bool hR = box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, o, id, tBest, tnR);
-        const int cl = __float_as_int(n3.x), cr = __float_as_int(n3.y);
-#pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            const bool h = side ? hR : hL;
-            const int c = side ? cr : cl;
-            const float tn = side ? tnR : tnL;
-            if (h && c < 0 && tn < tBest) {
-                const uint32_t ref = ~(uint32_t)c;
-                const uint32_t first = ref >> 3, cnt = (ref & 7u) + 1u;
-                for (uint32_t k = 0; k < cnt; ++k) {
-                    const float4 *tp = S.tris + 4 * (size_t)(first + k);
-                    float t;
-                    if (COUNT) ++st.tris;
-                    if (tri_test(tp[0], tp[1], tp[2], o, d, t) && t < tBest) {
-                        tBest = t;
-                        triBest = (int)(first + k);
-                    }
-                }
-            }
-        }
-        hL = hL && cl >= 0 && tnL < tBest;
-        hR = hR && cr >= 0 && tnR < tBest;
-        if (hL && hR) {
-            const bool leftFirst = tnL <= tnR;
-            stack[sp * kBlock] = leftFirst ? cr : cl;
-            ++sp;
-            cur = leftFirst ? cl : cr;
-        } else if (hL) {
-            cur = cl;
-        } else if (hR) {
-            cur = cr;
-        } else {
-            if (sp == 0) break;
-            --sp;
-            cur = stack[sp * kBlock];
-        }
-    }
+    Traversal<COUNT> T;
+    T.start(o, d, stack);
+    while (!T.done()) T.step(S, st);
+    tBest = T.tBest;
+    triBest = T.triBest;
 }
 
 // ---------------------------------------------------------------------------------------------
