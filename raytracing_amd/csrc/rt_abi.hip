@@ -30,6 +30,7 @@ struct rt_scene {
     uint64_t device_bytes = 0;
     bool counting = false;
     uint32_t nmat = 0;
+    uint64_t host_segments = 0;  // segments of launches whose ray count the host knows (one per ray)
 };
 
 namespace {
@@ -112,6 +113,8 @@ int ensure_wavefront(rt_scene *s, uint32_t npix) {
     return RT_OK;
 }
 
+constexpr size_t kCounterWords = (size_t)rtd::kCounterShards * rtd::kCounterStride;
+
 int check_image(uint32_t W, uint32_t H) {
     if (W == 0 || H == 0) return fail(RT_ERR_INVALID, "image width and height must be positive");
     if ((uint64_t)W * H > (1ull << 28)) return fail(RT_ERR_LIMIT, "image has more than 2^28 pixels");
@@ -184,13 +187,13 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     RT_TRY(dev_alloc(s, &s->d_tris, f.tris.size() / 4));
     RT_TRY(dev_alloc(s, &s->d_lights, f.lights.size()));
     RT_TRY(dev_alloc(s, &s->d_mats, mats.size()));
-    RT_TRY(dev_alloc(s, &s->d_counters, (size_t)8));
+    RT_TRY(dev_alloc(s, &s->d_counters, kCounterWords));
     RT_TRY(hipMemcpy(s->d_nodes, f.nodes.data(), f.nodes.size() * sizeof(float), hipMemcpyHostToDevice));
     RT_TRY(hipMemcpy(s->d_tris, f.tris.data(), f.tris.size() * sizeof(float), hipMemcpyHostToDevice));
     if (!f.lights.empty())
         RT_TRY(hipMemcpy(s->d_lights, f.lights.data(), f.lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     RT_TRY(hipMemcpy(s->d_mats, mats.data(), mats.size() * sizeof(rtd::DevMaterial), hipMemcpyHostToDevice));
-    RT_TRY(hipMemset(s->d_counters, 0, 8 * sizeof(unsigned long long)));
+    RT_TRY(hipMemset(s->d_counters, 0, kCounterWords * sizeof(unsigned long long)));
 #undef RT_TRY
     rtd::DevScene &v = s->view;
     v.nodes = s->d_nodes;
@@ -249,6 +252,7 @@ int rt_intersect_rays_dev(rt_scene *s, uint64_t n, const float *d_origins, const
     if (n > (1ull << 31)) return fail(RT_ERR_LIMIT, "rt_intersect_rays_dev: more than 2^31 rays in one call");
     DeviceGuard g(s->device);
     RT_HIP(rt::launch_intersect(s->view, n, d_origins, d_directions, d_prim_id, d_t, s->counting, (hipStream_t)stream));
+    s->host_segments += n;
     return RT_OK;
 }
 
@@ -285,6 +289,7 @@ int rt_trace_primary_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t 
     if (rc != RT_OK) return rc;
     DeviceGuard g(s->device);
     RT_HIP(rt::launch_primary(s->view, width, height, d_prim_id, d_t, s->counting, (hipStream_t)stream));
+    s->host_segments += (uint64_t)width * height;
     return RT_OK;
 }
 
@@ -406,17 +411,21 @@ int rt_set_counting(rt_scene *s, int enable) {
 int rt_counters_reset(rt_scene *s, void *stream) {
     if (!s) return fail(RT_ERR_INVALID, "rt_counters_reset: null scene");
     DeviceGuard g(s->device);
-    RT_HIP(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), (hipStream_t)stream));
+    RT_HIP(hipMemsetAsync(s->d_counters, 0, kCounterWords * sizeof(unsigned long long), (hipStream_t)stream));
+    s->host_segments = 0;
     return RT_OK;
 }
 
 int rt_counters_read(rt_scene *s, rt_counters *out) {
     if (!s || !out) return fail(RT_ERR_INVALID, "rt_counters_read: null argument");
     DeviceGuard g(s->device);
-    unsigned long long h[4];
+    std::vector<unsigned long long> raw(kCounterWords);
     RT_HIP(hipDeviceSynchronize());
-    RT_HIP(hipMemcpy(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost));
-    out->segments = h[0];
+    RT_HIP(hipMemcpy(raw.data(), s->d_counters, kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long h[4] = {0, 0, 0, 0};
+    for (int sh = 0; sh < rtd::kCounterShards; ++sh)
+        for (int k = 0; k < 4; ++k) h[k] += raw[(size_t)sh * rtd::kCounterStride + k];
+    out->segments = h[0] + s->host_segments;
     out->nodes = h[1];
     out->tri_tests = h[2];
     out->light_tests = h[3];

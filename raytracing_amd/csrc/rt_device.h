@@ -17,6 +17,8 @@ constexpr float kInf = 10000.f;    // INF, main.cpp:23
 constexpr float kOneOverPi = 0.318309886183790671537767526745028724f;  // glm::one_over_pi<float>()
 constexpr int kBlock = 256;        // threads per workgroup of every traversal kernel (4 waves)
 constexpr int kStack = 32;         // traversal stack entries per lane (host checks tree height)
+constexpr int kCounterShards = 256;   // statistics counters: shards (power of two) ...
+constexpr int kCounterStride = 16;    // ... of 16 x u64 = one 128-byte line each
 
 // ---------------------------------------------------------------------------------------------
 // vec3 in glm 0.9.9.8 operation order (one rounding per operation, sums left to right)
@@ -114,7 +116,7 @@ struct DevScene {
     const float4 *tris;       // 4 x float4 per triangle, leaf order
     const uint32_t *lights;   // leaf-order positions of the emissive triangles
     const DevMaterial *mats;
-    unsigned long long *counters;  // [0] segments [1] nodes [2] tri tests [3] light tests
+    unsigned long long *counters;  // kCounterShards x kCounterStride; per shard [0] segments [1] nodes [2] tri tests [3] light tests
     uint32_t nlights;
     float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];
     float tan_x, tan_y;

@@ -37,14 +37,19 @@ __device__ __forceinline__ bool tile_pixel(uint32_t W, uint32_t H, uint32_t &px,
     return px < W && py < H;
 }
 
+// Statistics counters are sharded: workgroup b adds into shard b % kCounterShards (one 128-byte
+// line each), because every wave adding to ONE word serialises at the memory side (a single
+// address takes about 88 atomics per microsecond, which alone cost a millisecond per 1080p
+// launch).  The host sums the shards when it reads them.
 __device__ __forceinline__ void add_counters(const DevScene &S, uint32_t segs, const TraceStats &st, uint32_t lights,
                                              bool count) {
-    atomicAdd(&S.counters[0], (unsigned long long)segs);
+    unsigned long long *c = S.counters + (size_t)(blockIdx.x & (rtd::kCounterShards - 1)) * rtd::kCounterStride;
+    if (segs) atomicAdd(&c[0], (unsigned long long)segs);
     if (count) {
-        atomicAdd(&S.counters[1], (unsigned long long)st.nodes);
-        atomicAdd(&S.counters[2], (unsigned long long)st.tris);
+        atomicAdd(&c[1], (unsigned long long)st.nodes);
+        atomicAdd(&c[2], (unsigned long long)st.tris);
     }
-    atomicAdd(&S.counters[3], (unsigned long long)lights);
+    if (lights) atomicAdd(&c[3], (unsigned long long)lights);
 }
 
 __device__ __forceinline__ uint32_t tri_loader_id(const DevScene &S, int tri) {
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, uint64_t n, co
     closest_hit<COUNT>(S, ro, rd, s_stack + threadIdx.x, t, tri, st);
     prim_id[i] = tri >= 0 ? tri_loader_id(S, tri) : 0xFFFFFFFFu;
     tout[i] = t;
-    add_counters(S, 1u, st, 0u, COUNT);
+    if (COUNT) add_counters(S, 0u, st, 0u, true);  // the host adds one segment per ray
 }
 
 template <bool COUNT>
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, uint32_t W, uint
     closest_hit<COUNT>(S, ro, rd, s_stack + threadIdx.x, t, tri, st);
     prim_id[pix] = tri >= 0 ? tri_loader_id(S, tri) : 0xFFFFFFFFu;
     tout[pix] = t;
-    add_counters(S, 1u, st, 0u, COUNT);
+    if (COUNT) add_counters(S, 0u, st, 0u, true);  // the host adds one segment per pixel
 }
 
 // One lane owns one pixel and runs its samples back to back; when a path ends the lane starts
@@ -174,29 +179,75 @@ __global__ __launch_bounds__(kBlock) void wf_generate(DevScene S, rt::RenderPara
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         qcount[0] = npaths;
         qcount[1] = 0u;
+        qcount[2] = 0u;  // work cursor of the first extend pass
     }
 }
 
 // Traces the rays of the input queue (null queue = identity: slots 0..count-1) and stores the hit.
+// Persistent waves with per-lane dynamic ray fetch: a lane whose ray has finished takes the next
+// ray of the queue instead of idling until the slowest lane of its wave is done.  A wave grabs
+// kChunk consecutive queue entries with one atomic on the work cursor and deals them to its idle
+// lanes (ballot + prefix count) whenever at least kRefill lanes are idle.
+constexpr uint32_t kChunk = 128;
+constexpr int kRefill = 12;
+
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const uint32_t *__restrict__ queue,
                                                      const uint32_t *__restrict__ qcount_in,
-                                                     uint32_t *__restrict__ qcount_zero) {
+                                                     uint32_t *__restrict__ qcount_zero, uint32_t *__restrict__ cursor) {
     __shared__ int s_stack[kStack * kBlock];
     const uint32_t count = *qcount_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) *qcount_zero = 0u;  // the queue the next shade pass fills
-    uint32_t segs = 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    Traversal<COUNT> T;
+    T.idle();
+    T.stack = s_stack + threadIdx.x;
+    uint32_t slot = 0, segs = 0;
+    bool hasRay = false;
+    uint32_t chunkNext = 0, chunkEnd = 0;  // wave-uniform
+    bool exhausted = false;                // wave-uniform: the cursor ran past the queue
     TraceStats st{0, 0};
-    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < count; j += gridDim.x * kBlock) {
-        const uint32_t i = queue ? queue[j] : j;
-        const v3 o = mk(V.ray[i], V.ray[V.cap + i], V.ray[2 * (size_t)V.cap + i]);
-        const v3 d = mk(V.ray[3 * (size_t)V.cap + i], V.ray[4 * (size_t)V.cap + i], V.ray[5 * (size_t)V.cap + i]);
-        float t;
-        int tri;
-        closest_hit<COUNT>(S, o, d, s_stack + threadIdx.x, t, tri, st);
-        V.hit_t[i] = t;
-        V.hit_tri[i] = tri;
-        ++segs;
+    for (;;) {
+        if (hasRay && T.done()) {
+            V.hit_t[slot] = T.tBest;
+            V.hit_tri[slot] = T.triBest;
+            hasRay = false;
+            ++segs;
+        }
+        const unsigned long long idleMask = __ballot(!hasRay);
+        const int nIdle = __builtin_popcountll(idleMask);
+        if (nIdle == 64 && exhausted) break;
+        if (!exhausted && nIdle >= kRefill) {
+            const uint32_t rank = (uint32_t)__builtin_popcountll(idleMask & ((1ull << lane) - 1ull));
+            uint32_t given = 0;
+            while (given < (uint32_t)nIdle) {
+                if (chunkNext == chunkEnd) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(cursor, kChunk);
+                    base = __shfl(base, 0);
+                    if (base >= count) {
+                        exhausted = true;
+                        break;
+                    }
+                    chunkNext = base;
+                    chunkEnd = (count - base < kChunk) ? count : base + kChunk;
+                }
+                const uint32_t avail = chunkEnd - chunkNext;
+                const uint32_t take = avail < (uint32_t)nIdle - given ? avail : (uint32_t)nIdle - given;
+                if (!hasRay && rank >= given && rank < given + take) {
+                    const uint32_t j = chunkNext + (rank - given);
+                    slot = queue ? queue[j] : j;
+                    const v3 o = mk(V.ray[slot], V.ray[V.cap + slot], V.ray[2 * (size_t)V.cap + slot]);
+                    const v3 d = mk(V.ray[3 * (size_t)V.cap + slot], V.ray[4 * (size_t)V.cap + slot],
+                                    V.ray[5 * (size_t)V.cap + slot]);
+                    T.start(o, d, s_stack + threadIdx.x);
+                    hasRay = true;
+                }
+                chunkNext += take;
+                given += take;
+            }
+        }
+        T.step(S, st);
     }
     if (segs) add_counters(S, segs, st, 0u, COUNT);
 }
@@ -205,8 +256,10 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
 // one ballot per wave, one atomic per wave, lanes write at their prefix offset.
 __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const uint32_t *__restrict__ queue,
                                                     const uint32_t *__restrict__ qcount_in,
-                                                    uint32_t *__restrict__ queue_out, uint32_t *__restrict__ qcount_out) {
+                                                    uint32_t *__restrict__ queue_out, uint32_t *__restrict__ qcount_out,
+                                                    uint32_t *__restrict__ cursor) {
     const uint32_t count = *qcount_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *cursor = 0u;  // work cursor of the next extend pass
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t lightTests = 0;
     // every lane of a wave runs the same number of iterations so the ballot sees the whole wave
@@ -251,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const u
             if (alive) queue_out[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = i;
         }
     }
-    if (lightTests) atomicAdd(&S.counters[3], (unsigned long long)lightTests);
+    if (lightTests) add_counters(S, 0u, TraceStats{0, 0}, lightTests, false);
 }
 
 // radiance_sum[pix] (+)= sum over the batch's sample slots, in slot order (deterministic).
@@ -280,6 +333,7 @@ __global__ __launch_bounds__(kBlock) void k_tonemap(const float *__restrict__ su
 
 inline uint32_t pixel_grid(uint32_t W, uint32_t H) { return ((W + 15u) / 16u) * ((H + 15u) / 16u); }
 constexpr uint32_t kPersistentBlocks = 256u * 8u;  // 256 CUs x 8 workgroups for grid-stride kernels
+constexpr uint32_t kExtendBlocks = 256u * 5u;      // 256 CUs x 5 workgroups of 32 KB LDS each
 
 }  // namespace
 
@@ -322,19 +376,22 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
         const uint32_t npaths = ns * npix;
         const uint32_t grid = (npaths + kBlock - 1) / kBlock < kPersistentBlocks ? (npaths + kBlock - 1) / kBlock
                                                                                  : kPersistentBlocks;
+        // extend runs persistent waves: as many workgroups as stay resident (LDS allows 5 per CU)
+        const uint32_t egrid = grid < kExtendBlocks ? grid : kExtendBlocks;
         hipLaunchKernelGGL(wf_generate, dim3(grid), dim3(kBlock), 0, stream, S, rp, V, npaths, rp.spp_begin + done,
                            wb.qcount);
-        for (uint32_t b = 0; b < rp.max_depth; ++b) {
+        const uint32_t bounces = rp.max_depth ? rp.max_depth : 1u;  // depth 0 still traces the camera ray
+        for (uint32_t b = 0; b < bounces; ++b) {
             const uint32_t in = b & 1u, out = in ^ 1u;
             const uint32_t *qin = (b == 0) ? nullptr : wb.queue[in];
             if (count)
-                hipLaunchKernelGGL(wf_extend<true>, dim3(grid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in,
-                                   wb.qcount + out);
+                hipLaunchKernelGGL(wf_extend<true>, dim3(egrid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in,
+                                   wb.qcount + out, wb.qcount + 2);
             else
-                hipLaunchKernelGGL(wf_extend<false>, dim3(grid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in,
-                                   wb.qcount + out);
+                hipLaunchKernelGGL(wf_extend<false>, dim3(egrid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in,
+                                   wb.qcount + out, wb.qcount + 2);
             hipLaunchKernelGGL(wf_shade, dim3(grid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in, wb.queue[out],
-                               wb.qcount + out);
+                               wb.qcount + out, wb.qcount + 2);
         }
         const uint32_t agrid = (npix + kBlock - 1) / kBlock < kPersistentBlocks ? (npix + kBlock - 1) / kBlock
                                                                                 : kPersistentBlocks;
