@@ -19,8 +19,8 @@ namespace rt {
 
 // Traversal limits the kernels are built for; checked on the host before any launch.
 constexpr uint32_t kMaxLeafTris = 4;     // the reference's leaf size (main.cpp:618)
-constexpr uint32_t kStackEntries = 32;   // per-lane traversal stack held in LDS
-constexpr uint32_t kMaxTreeHeight = 32;  // builder guarantee: pending stack entries <= height
+constexpr uint32_t kStackEntries = 24;   // per-lane traversal stack held in LDS
+constexpr uint32_t kMaxTreeHeight = 24;  // builder guarantee: pending stack entries <= height
 constexpr uint32_t kMaxTriangles = 1u << 28;
 
 // Flattened acceleration structure, exactly as it lies in HBM.

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
     const uint32_t lane = threadIdx.x & 63u;
     Traversal<COUNT> T;
     T.idle();
-    T.stack = s_stack + threadIdx.x;
+    T.bind(s_stack + threadIdx.x);
     uint32_t slot = 0, segs = 0;
     bool hasRay = false;
     uint32_t chunkNext = 0, chunkEnd = 0;  // wave-uniform
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
                     const v3 o = mk(V.ray[slot], V.ray[V.cap + slot], V.ray[2 * (size_t)V.cap + slot]);
                     const v3 d = mk(V.ray[3 * (size_t)V.cap + slot], V.ray[4 * (size_t)V.cap + slot],
                                     V.ray[5 * (size_t)V.cap + slot]);
-                    T.start(o, d, s_stack + threadIdx.x);
+                    T.start(o, d);
                     hasRay = true;
                 }
                 chunkNext += take;
@@ -332,8 +332,9 @@ __global__ __launch_bounds__(kBlock) void k_tonemap(const float *__restrict__ su
 }
 
 inline uint32_t pixel_grid(uint32_t W, uint32_t H) { return ((W + 15u) / 16u) * ((H + 15u) / 16u); }
+inline uint32_t ceil_blocks(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 constexpr uint32_t kPersistentBlocks = 256u * 8u;  // 256 CUs x 8 workgroups for grid-stride kernels
-constexpr uint32_t kExtendBlocks = 256u * 5u;      // 256 CUs x 5 workgroups of 32 KB LDS each
+constexpr uint32_t kExtendBlocks = 256u * 6u;      // 256 CUs x 6 resident workgroups (24 KB of LDS each)
 
 }  // namespace
 
@@ -376,7 +377,7 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
         const uint32_t npaths = ns * npix;
         const uint32_t grid = (npaths + kBlock - 1) / kBlock < kPersistentBlocks ? (npaths + kBlock - 1) / kBlock
                                                                                  : kPersistentBlocks;
-        // extend runs persistent waves: as many workgroups as stay resident (LDS allows 5 per CU)
+        // extend runs persistent waves: as many workgroups as stay resident
         const uint32_t egrid = grid < kExtendBlocks ? grid : kExtendBlocks;
         hipLaunchKernelGGL(wf_generate, dim3(grid), dim3(kBlock), 0, stream, S, rp, V, npaths, rp.spp_begin + done,
                            wb.qcount);
