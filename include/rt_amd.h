@@ -101,7 +101,7 @@ typedef struct rt_scene_stats {
     uint32_t ntri;
     uint32_t nlights;
     uint32_t nnodes;      /* 64-byte two-child nodes */
-    uint32_t tree_height; /* edges on the longest root-to-leaf path */
+    uint32_t tree_height; /* inner-node levels on the longest root-to-leaf path */
     double build_seconds; /* host BVH build + flatten */
     uint64_t device_bytes;
 } rt_scene_stats;
@@ -134,6 +134,16 @@ int rt_scene_get_stats(const rt_scene *s, rt_scene_stats *out);
 /* Copies of the flattened structure for checkers: nodes (nnodes * 16 floats), triangles in
  * leaf order (ntri * 16 floats).  Either pointer may be NULL. */
 int rt_scene_get_flat(const rt_scene *s, float *nodes, float *tris);
+
+/* Host-only view of the same build (no GPU call), for tools and checkers: builds the
+ * acceleration structure of `desc` and hands out the flattened arrays exactly as rt_scene_create
+ * would upload them.  info[0] = node count, [1] = triangle count, [2] = light count,
+ * [3] = tree height (inner levels).  nodes: nnodes*16 floats, tris: ntri*16 floats (leaf order),
+ * lights: leaf-order positions of the emissive triangles in loader order; any may be NULL. */
+typedef struct rt_flat rt_flat;
+int rt_flat_build(const rt_scene_desc *desc, rt_flat **out);
+int rt_flat_get(const rt_flat *f, uint32_t info[4], float *nodes, float *tris, uint32_t *lights);
+void rt_flat_free(rt_flat *f);
 
 /* ---- closest hit: stands in for intersectScene / BVH::intersect, main.cpp:1113, 560-605 ---- */
 /* n rays, origins and directions as n*3 floats; prim_id[i] = loader-order triangle id or

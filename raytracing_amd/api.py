@@ -81,6 +81,27 @@ def load_gltf(path, width, height):
     return HostScene(tv, tm, mats, cam)
 
 
+def build_flat(host_scene):
+    """Host-only acceleration-structure build (no GPU): returns dict(nodes (n,16) f32, tris (m,16) f32,
+    lights (k,) u32 leaf-order positions, height)."""
+    if isinstance(host_scene, dict):
+        host_scene = HostScene(**host_scene)
+    L = _lib.lib()
+    h = C.c_void_p()
+    d = host_scene._desc()
+    check(L.rt_flat_build(C.byref(d), C.byref(h)))
+    try:
+        info = np.zeros(4, dtype=np.uint32)
+        check(L.rt_flat_get(h, _p(info), None, None, None))
+        nodes = np.empty((int(info[0]), 16), dtype=np.float32)
+        tris = np.empty((int(info[1]), 16), dtype=np.float32)
+        lights = np.empty(int(info[2]), dtype=np.uint32)
+        check(L.rt_flat_get(h, None, _p(nodes), _p(tris), _p(lights) if lights.size else None))
+    finally:
+        L.rt_flat_free(h)
+    return dict(nodes=nodes, tris=tris, lights=lights, height=int(info[3]))
+
+
 class Scene:
     """Device-resident scene: BVH + triangles + materials + lights + camera on one GPU."""
 

@@ -353,3 +353,51 @@ void build_flat_scene(const rt_scene_desc &desc, FlatScene &out) {
 }
 
 }  // namespace rt
+
+// ---- host-only C entry points over the builder (declared in include/rt_amd.h) -----------------
+struct rt_flat {
+    rt::FlatScene flat;
+};
+
+extern "C" {
+
+int rt_flat_build(const rt_scene_desc *desc, rt_flat **out) {
+    if (!desc || !out) {
+        rt::set_error("rt_flat_build: null argument");
+        return RT_ERR_INVALID;
+    }
+    *out = nullptr;
+    rt_flat *f = new rt_flat();
+    try {
+        rt::build_flat_scene(*desc, f->flat);
+    } catch (const std::exception &e) {
+        delete f;
+        std::string msg = e.what();
+        rt::set_error("rt_flat_build: " + msg);
+        return msg.find("too many") != std::string::npos ? RT_ERR_LIMIT : RT_ERR_INVALID;
+    }
+    *out = f;
+    return RT_OK;
+}
+
+int rt_flat_get(const rt_flat *f, uint32_t info[4], float *nodes, float *tris, uint32_t *lights) {
+    if (!f) {
+        rt::set_error("rt_flat_get: null argument");
+        return RT_ERR_INVALID;
+    }
+    const rt::FlatScene &s = f->flat;
+    if (info) {
+        info[0] = s.nnodes;
+        info[1] = s.ntri;
+        info[2] = (uint32_t)s.lights.size();
+        info[3] = s.tree_height;
+    }
+    if (nodes) std::memcpy(nodes, s.nodes.data(), (size_t)s.nnodes * 16 * sizeof(float));
+    if (tris) std::memcpy(tris, s.tris.data(), (size_t)s.ntri * 16 * sizeof(float));
+    if (lights && !s.lights.empty()) std::memcpy(lights, s.lights.data(), s.lights.size() * sizeof(uint32_t));
+    return RT_OK;
+}
+
+void rt_flat_free(rt_flat *f) { delete f; }
+
+}  // extern "C"

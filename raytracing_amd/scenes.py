@@ -245,17 +245,18 @@ def cornell_box(path):
 
 def heightfield_scene(path, nx=224, nz=224):
     """2*nx*nz + 2 triangles: a diffuse sinusoidal terrain lit by one emissive quad; the
-    default 224 x 224 gives 100 354 triangles.  The camera looks down at the terrain."""
+    default 224 x 224 gives 100 354 triangles.  The camera looks down at the terrain, which
+    fills the 16:9 frame."""
     g = GltfBuilder()
     ground = g.material(DIFFUSER, (0.6, 0.55, 0.4))
     light = g.material(DIFFUSER, (0.8, 0.8, 0.8), emission=(1.0, 0.95, 0.9), strength=20.0)
-    pos, idx = heightfield(nx, nz)
+    pos, idx = heightfield(nx, nz, -3.0, 3.0, -3.4, 1.6)
     terrain = g.mesh([(pos, idx, ground)])
     lamp = g.mesh([quad((-0.4, 1.2, -0.4), (0.4, 1.2, -0.4), (0.4, 1.2, 0.4), (-0.4, 1.2, 0.4)) + (light,)])
     g.node(mesh=terrain)
     g.node(mesh=lamp)
     cam = g.camera(0.75)
-    g.node(camera=cam, translation=(0.0, 0.55, 2.3), rotation=_quat_axis_angle((1, 0, 0), -0.42))
+    g.node(camera=cam, translation=(0.0, 0.9, 2.2), rotation=_quat_axis_angle((1, 0, 0), -0.68))
     return g.write(path)
 
 

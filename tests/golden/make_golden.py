@@ -1,0 +1,69 @@
+"""Regenerates the fixtures of tests/golden/.  Run from the repo root: python tests/golden/make_golden.py
+
+The reference ships no tests or golden data, and it cannot be built in this image (glm is
+absent), so nothing here was produced BY the reference:
+
+  rng_kat.json       known answers of std::minstd_rand + the libstdc++ 11 distributions exactly as the
+                     reference instantiates them (main.cpp:98-111).  The entries for seeds 0, 64037 and
+                     2073599 are the table recorded by the survey of the reference (a g++ 11.4 program
+                     using <random> directly); the script re-derives them through the oracle, which
+                     links the same library, and refuses to write a file that disagrees with the table.
+  cornell_64x48.npz  oracle outputs for the generated Cornell scene: primary-hit ids / distances and
+                     4-spp radiance sums in both RNG modes.  They pin the ORACLE against regressions
+                     and give the GPU tests a committed target; they do not pin it to the reference.
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+SURVEY_TABLE = {  # seed: (raw[4], uniform bits[3], normal bits[3], engine draws for the 3 normals, ui2, ui12)
+    0: ([48271, 182605794, 1291394886, 1914720637], [0x37bc8e00, 0x3dae257e, 0x3f19f23f],
+        [0x3f642e37, 0xc01f238b, 0x3f63ed65], 10, [0, 0, 1, 1], [0, 1, 7, 10]),
+    64037: ([943646380, 478772463, 1754036106, 239122457], [0x3ee0fb9b, 0x3e644be7, 0x3f5118ef],
+            [0xbfbc5305, 0xbfdd2239, 0xbf748c5e], 10, [0, 0, 1, 0], [5, 2, 9, 1]),
+    2073599: ([1310449567, 432742625, 345817006, 542308495], [0x3f1c37bf, 0x3e4e5907, 0x3e24e5fd],
+              [0xbfa1726d, 0xbefca7ba, 0x3ca1272f], 6, [1, 0, 0, 0], [7, 2, 1, 3]),
+}
+
+
+def main():
+    from oracle import gltf_ref, oracle
+    from raytracing_amd import scenes
+
+    kat = {}
+    for seed in (0, 1, 64037, 2073599, 2147483646, 2147483647, 4294967295):
+        k = oracle.rng_kat(seed)
+        kat[str(seed)] = dict(raw=[int(x) for x in k["raw"]], uni_bits=[int(x) for x in k["uni"].view(np.uint32)],
+                              nrm_bits=[int(x) for x in k["nrm"].view(np.uint32)], nrm_draws=int(k["nrm_draws"]),
+                              ui2=[int(x) for x in k["ui2"]], ui12=[int(x) for x in k["ui12"]])
+    for seed, (raw, uni, nrm, draws, ui2, ui12) in SURVEY_TABLE.items():
+        e = kat[str(seed)]
+        assert (e["raw"], e["uni_bits"], e["nrm_bits"], e["nrm_draws"], e["ui2"], e["ui12"]) == \
+            (raw, uni, nrm, draws, ui2, ui12), "oracle RNG disagrees with the recorded table for seed %d" % seed
+    kat["counter_seed"] = [[p, s, sd, oracle.counter_seed(p, s, sd)]
+                           for p, s, sd in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (2073599, 1023, 0x5EED), (12345, 7, 99))]
+    with open(os.path.join(HERE, "rng_kat.json"), "w") as f:
+        json.dump(kat, f, indent=1)
+
+    W, H, spp = 64, 48, 4
+    with tempfile.TemporaryDirectory() as d:
+        sc = gltf_ref.parse_gltf(scenes.cornell_box(os.path.join(d, "cornell.gltf")), W, H)
+    orc = oracle.OracleScene(sc["tri_verts"], sc["tri_material"], sc["materials"], sc["camera"])
+    ids, t, tie, _ = orc.trace_primary(W, H)
+    ref, cnt0 = orc.render(W, H, spp, max_depth=6, rng_mode=0)
+    ctr, cnt1 = orc.render(W, H, spp, max_depth=8, rng_mode=1, seed=0x5EED, spp_begin=2)
+    np.savez_compressed(os.path.join(HERE, "cornell_64x48.npz"), ids=ids, t=t, tie=tie, sum_reference_rng=ref,
+                        sum_counter_rng=ctr, segments=np.array([cnt0["segments"], cnt1["segments"]], dtype=np.uint64),
+                        tri_verts=sc["tri_verts"])
+    print("wrote rng_kat.json and cornell_64x48.npz")
+
+
+if __name__ == "__main__":
+    main()

@@ -133,3 +133,154 @@ def test_tonemap_matches_oracle(scene_dir, oracle_mod):
     assert np.allclose(f_g, f_o, rtol=2e-6, atol=1e-7)
     assert (b_g != b_o).mean() < 1e-3
     assert np.abs(b_g.astype(int) - b_o.astype(int)).max() <= 1
+
+
+# ---------------------------------------------------------------------------------------------
+# committed fixtures, edge cases, full-size checks
+# ---------------------------------------------------------------------------------------------
+def test_golden_cornell_fixture(scene_dir, oracle_mod):
+    """The committed oracle outputs (tests/golden/cornell_64x48.npz) as the target."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cornell_64x48.npz"))
+    host, gpu, orc = _load(scene_dir, oracle_mod, "cornell", 64, 48)
+    assert np.array_equal(host.tri_verts, g["tri_verts"])
+    ids, t = gpu.trace_primary(64, 48)
+    _compare_hits(ids, t, g["ids"], g["t"], g["tie"])
+    for mode, key, kw in ((0, "sum_reference_rng", dict(max_depth=6)),
+                          (1, "sum_counter_rng", dict(max_depth=8, seed=0x5EED, spp_begin=2))):
+        out = gpu.render(64, 48, 4, rng_mode=mode, **kw)
+        rel = np.abs(out - g[key]) / np.maximum(np.abs(g[key]), 1e-3)
+        assert np.median(rel) <= 1e-5 and (rel.max(axis=1) > 1e-3).mean() <= 0.01
+
+
+def test_config2_full_size_primary_hits(scene_dir, oracle_mod):
+    """BASELINE config 2 at full size: 100 354-triangle mesh, 1920x1080 primary rays, hit ids and
+    distances bit for bit against the oracle (which builds its own, different, BVH)."""
+    W, H = 1920, 1080
+    host, gpu, orc = _load(scene_dir, oracle_mod, "heightfield100k", W, H)
+    assert host.tri_verts.shape[0] == 100354
+    ids_g, t_g = gpu.trace_primary(W, H)
+    ids_o, t_o, tie, _ = orc.trace_primary(W, H)
+    nties = _compare_hits(ids_g, t_g, ids_o, t_o, tie)
+    assert nties <= 20
+    assert (ids_g != 0xFFFFFFFF).mean() > 0.5
+    # same rays through the explicit-ray entry point give the same answer
+    o, d = orc.primary_rays(W, H)
+    sel = np.random.RandomState(0).choice(W * H, 50000, replace=False)
+    ids_r, t_r = gpu.intersect(o[sel], d[sel])
+    assert np.array_equal(ids_r, ids_g[sel]) and np.array_equal(t_r, t_g[sel])
+
+
+def test_degenerate_scenes(oracle_mod):
+    """Empty scene, one triangle, no lights, only lights."""
+    import raytracing_amd as rt
+    mats = np.zeros(2, dtype=rt.api.MATERIAL_DTYPE)
+    mats["color"] = 0.5
+    mats["ior"] = 1.5
+    mats["emission"][1] = (3, 2, 1)
+    cam = dict(position=[0, 0, 3], right=[1, 0, 0], up=[0, 1, 0], forward=[0, 0, -1], tan_x=0.5, tan_y=0.5)
+    W = H = 32
+    empty = rt.HostScene(np.zeros((0, 3, 3), np.float32), np.zeros(0, np.uint32), mats, cam)
+    with rt.Scene(empty) as s:
+        ids, t = s.trace_primary(W, H)
+        assert (ids == 0xFFFFFFFF).all() and (t == np.float32(1e4)).all()
+        for pipe in (0, 1):
+            assert not s.render(W, H, 3, rng_mode=1, pipeline=pipe).any()
+    tri = np.array([[[-1, -1, 0], [1, -1, 0], [0, 1, 0]]], np.float32)
+    for mat in (0, 1):   # a lone diffuse triangle (no lights), a lone emitter
+        host = rt.HostScene(tri, np.array([mat], np.uint32), mats, cam)
+        orc = oracle_mod.OracleScene(tri, np.array([mat], np.uint32), mats, cam)
+        with rt.Scene(host) as s:
+            ids, t = s.trace_primary(W, H)
+            ids_o, t_o, tie, _ = orc.trace_primary(W, H)
+            _compare_hits(ids, t, ids_o, t_o, tie)
+            assert 0 < (ids == 0).sum() < W * H
+            ref, _ = orc.render(W, H, 4, max_depth=6, rng_mode=0)
+            out = s.render(W, H, 4, max_depth=6, rng_mode=0)
+            assert np.allclose(out, ref, rtol=1e-5, atol=1e-6)
+            assert out.any() == (mat == 1)
+
+
+def test_depth_parameter_and_zero_samples(scene_dir, oracle_mod):
+    W, H = 48, 36
+    host, gpu, orc = _load(scene_dir, oracle_mod, "cornell", W, H)
+    for depth in (0, 1, 2, 16):
+        ref, c_o = orc.render(W, H, 3, max_depth=depth, rng_mode=1, seed=4)
+        for pipe in (0, 1):
+            gpu.reset_counters()
+            out = gpu.render(W, H, 3, max_depth=depth, rng_mode=1, seed=4, pipeline=pipe)
+            rel = np.abs(out - ref) / np.maximum(np.abs(ref), 1e-3)
+            assert np.median(rel) <= 1e-5 and (rel.max(axis=1) > 1e-3).mean() <= 0.01, (depth, pipe)
+            assert abs(gpu.counters()["segments"] - c_o["segments"]) <= 0.002 * c_o["segments"] + 2
+    for pipe in (0, 1):
+        assert not gpu.render(W, H, 0, rng_mode=1, pipeline=pipe).any()
+    import raytracing_amd as rt
+    with pytest.raises(rt.RtError):
+        gpu.render(W, H, 2, rng_mode=0, spp_begin=1)            # the reference stream cannot start mid-pixel
+    with pytest.raises(rt.RtError):
+        gpu.render(W, H, 2, rng_mode=0, pipeline=1)             # wavefront needs the counter RNG
+
+
+def test_full_size_properties_1080p(scene_dir, oracle_mod):
+    """At BASELINE's frame size the oracle is too slow for a full comparison, so the 1080p run is
+    checked through properties: (1) partial sums of disjoint sample ranges add up to the full
+    range's sum, as the multi-GPU split needs; (2) both pipelines agree; (3) launches are
+    deterministic; (4) a crop of the frame agrees with the oracle rendering the same pixels is not
+    possible (the oracle renders whole frames), so instead the frame at 1/8 size is compared with
+    the oracle in test_render_counter_mode_matches_oracle and the ray counts per sample must agree
+    between the two frame sizes within sampling noise."""
+    W, H = 1920, 1080
+    host, gpu, orc = _load(scene_dir, oracle_mod, "cornell", W, H)
+    gpu.reset_counters()
+    full = gpu.render(W, H, 4, max_depth=8, rng_mode=1, seed=21, pipeline=1)
+    segs_full = gpu.counters()["segments"]
+    a = gpu.render(W, H, 1, max_depth=8, rng_mode=1, seed=21, spp_begin=0, pipeline=1)
+    b = gpu.render(W, H, 3, max_depth=8, rng_mode=1, seed=21, spp_begin=1, pipeline=1)
+    assert np.allclose(a + b, full, rtol=1e-5, atol=1e-6)
+    mega = gpu.render(W, H, 4, max_depth=8, rng_mode=1, seed=21, pipeline=0)
+    assert np.array_equal(mega, full) or np.allclose(mega, full, rtol=1e-6, atol=1e-7)
+    again = gpu.render(W, H, 4, max_depth=8, rng_mode=1, seed=21, pipeline=1)
+    assert np.array_equal(again, full)
+    assert np.isfinite(full).all() and (full >= 0).all()
+    _, c_small = orc.render(W // 8, H // 8, 4, max_depth=8, rng_mode=1, seed=21)
+    per_sample_small = c_small["segments"] / float((W // 8) * (H // 8) * 4)
+    per_sample_full = segs_full / float(W * H * 4)
+    assert abs(per_sample_full - per_sample_small) < 0.03 * per_sample_small
+
+
+def test_million_triangle_scene_matches_oracle_on_primary_rays(scene_dir, oracle_mod):
+    """The bench scene (1 006 600 triangles, mixed materials): primary hits at 480x270 bit for bit,
+    and a 2-spp depth-8 render within the radiance tolerances."""
+    W, H = 480, 270
+    host, gpu, orc = _load(scene_dir, oracle_mod, "spheres1m", W, H)
+    assert gpu.stats()["ntri"] == 1006600 and gpu.stats()["tree_height"] <= 24
+    ids_g, t_g = gpu.trace_primary(W, H)
+    ids_o, t_o, tie, _ = orc.trace_primary(W, H)
+    _compare_hits(ids_g, t_g, ids_o, t_o, tie)
+    ref, c_o = orc.render(W, H, 2, max_depth=8, rng_mode=1, seed=0x5EED)
+    for pipe in (0, 1):
+        gpu.reset_counters()
+        out = gpu.render(W, H, 2, max_depth=8, rng_mode=1, seed=0x5EED, pipeline=pipe)
+        rel = np.abs(out - ref) / np.maximum(np.abs(ref), 1e-3)
+        assert np.median(rel) <= 1e-5 and (rel.max(axis=1) > 1e-3).mean() <= 0.01
+        assert abs(gpu.counters()["segments"] - c_o["segments"]) <= 0.002 * c_o["segments"]
+
+
+def test_counting_launches_match_oracle_semantics(scene_dir, oracle_mod):
+    """The counted launches report nodes / triangle tests per ray for the roofline model.  Segment
+    and light-pdf test counts are properties of the estimator: they follow the oracle's except for
+    the rare sample whose path diverges (a Gaussian that differs by an ulp between libm's logf and
+    the device's flips a later branch), hence a 0.2 % band rather than equality."""
+    W, H = 64, 48
+    host, gpu, orc = _load(scene_dir, oracle_mod, "cornell", W, H)
+    ref, c_o = orc.render(W, H, 4, max_depth=6, rng_mode=0)
+    gpu.set_counting(True)
+    gpu.reset_counters()
+    gpu.render(W, H, 4, max_depth=6, rng_mode=0)
+    c = gpu.counters()
+    gpu.set_counting(False)
+    assert abs(c["segments"] - c_o["segments"]) <= 0.002 * c_o["segments"]
+    assert abs(c["light_tests"] - c_o["light_tests"]) <= 0.002 * c_o["light_tests"]
+    assert c["nodes"] >= c["segments"] and c["tri_tests"] > 0
+    # the oracle's own tree (2x inflated boxes, no pruning across subtrees) visits far more nodes
+    assert c["nodes"] < c_o["nodes"]

@@ -1,0 +1,239 @@
+"""CPU tests of the host side of the product: the C ABI library loads and exports what the header
+declares, the C++ scene loader agrees bit for bit with the numpy restatement of the reference
+loader, the BVH builder produces a valid flattened tree, error paths fail loudly.  No GPU."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, make_scene
+
+
+def test_library_exports_every_declared_symbol():
+    from raytracing_amd import _lib
+    header = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 25
+    L = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), "librt_amd.so does not export %s" % name
+    assert declared == set(_lib.SIGNATURES), "python binding and header disagree: %s" % (declared ^ set(_lib.SIGNATURES))
+
+
+def test_no_product_code_touches_the_oracle():
+    """The product path must never route through the CPU oracle."""
+    for base in ("raytracing_amd",):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for fn in files:
+                if fn.endswith((".py", ".cpp", ".hip", ".h", ".hpp")) or fn == "Makefile":
+                    text = open(os.path.join(dirpath, fn)).read()
+                    assert "oracle" not in text.lower(), "%s mentions the oracle" % os.path.join(dirpath, fn)
+
+
+@pytest.mark.parametrize("name,kw", [("cornell", {}), ("heightfield100k", {"nx": 300, "nz": 120}),
+                                     ("spheres1m", {"n_spheres": 30, "subdiv": 2, "ground": 8}),
+                                     ("glass", {"grid": 3, "subdiv": 2})])
+def test_loader_matches_reference_restatement(scene_dir, name, kw):
+    import raytracing_amd as rt
+    from oracle import gltf_ref
+    path = make_scene(scene_dir, name, **kw)
+    a = rt.load_gltf(path, 1920, 1080).as_dict()
+    b = gltf_ref.parse_gltf(path, 1920, 1080)
+    assert a["tri_verts"].shape == b["tri_verts"].shape and a["tri_verts"].shape[0] > 0
+    assert a["tri_verts"].tobytes() == b["tri_verts"].tobytes()
+    assert np.array_equal(a["tri_material"], b["tri_material"])
+    assert a["materials"].tobytes() == b["materials"].tobytes()
+    for k in a["camera"]:
+        assert np.array_equal(np.asarray(a["camera"][k]).view(np.uint32), np.asarray(b["camera"][k]).view(np.uint32)), k
+
+
+def test_loader_quirks(scene_dir):
+    """matrix nodes, nested children composed in index order, ignored accessor.byteOffset on indices,
+    default material type, JSON integers where floats are expected."""
+    import raytracing_amd as rt
+    from oracle import gltf_ref
+    from raytracing_amd.scenes import GltfBuilder, DIFFUSER, quad
+    g = GltfBuilder()
+    m0 = g.material(DIFFUSER, (1, 0, 0))
+    g.materials.append({})                                        # no pbr block -> METALLIC, white
+    g.materials.append({"pbrMetallicRoughness": {"metallicFactor": 1, "baseColorFactor": [0, 1, 0, 0.25]},
+                        "emissiveFactor": [1, 2, 3]})             # alpha < 1 -> DIELECTRIC; emissive without strength
+    pos, idx = quad((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0))
+    mesh = g.mesh([(pos, idx, m0), (pos + 2, idx, 1), (pos - 2, idx, 2)])
+    g.node(children=[1], translation=(1, 2, 3), scale=(2, 2, 2))                       # 0
+    g.node(children=[2], rotation=(0, 0.38268343, 0, 0.92387953))                       # 1
+    g.node(mesh=mesh, matrix=[1, 0, 0, 0, 0, 0, 1, 0, 0, -1, 0, 0, 5, 6, 7, 1])        # 2: column-major matrix
+    g.node(mesh=mesh)                                                                   # 3: untransformed copy
+    cam = g.camera(1)
+    g.node(camera=cam, translation=(0, 0, 10), rotation=(0.1, 0.2, 0.3, 0.9273618), scale=(1, 2, 1))
+    g.accessors[0]["byteOffset"] = 0
+    path = g.write(os.path.join(scene_dir, "quirks.gltf"))
+    a = rt.load_gltf(path, 320, 200).as_dict()
+    b = gltf_ref.parse_gltf(path, 320, 200)
+    assert a["tri_verts"].shape == (12, 3, 3)
+    assert a["tri_verts"].tobytes() == b["tri_verts"].tobytes()
+    assert a["materials"].tobytes() == b["materials"].tobytes()
+    assert list(a["materials"]["type"]) == [0, 1, 2]
+    assert np.array_equal(a["materials"]["emission"][2], np.array([1, 2, 3], np.float32))
+    for k in a["camera"]:
+        assert np.array_equal(np.asarray(a["camera"][k]), np.asarray(b["camera"][k])), k
+    # the un-transformed instance is the raw quad; the nested one went through three matrices
+    assert np.array_equal(a["tri_verts"][6], pos[[0, 1, 2]])
+    assert not np.array_equal(a["tri_verts"][0], pos[[0, 1, 2]])
+
+
+def test_loader_errors(scene_dir, tmp_path):
+    import raytracing_amd as rt
+    with pytest.raises(rt.RtError) as e:
+        rt.load_gltf(os.path.join(scene_dir, "does_not_exist.gltf"), 64, 64)
+    assert e.value.code == -2
+    bad = tmp_path / "bad.gltf"
+    bad.write_text("{ not json")
+    with pytest.raises(rt.RtError) as e:
+        rt.load_gltf(str(bad), 64, 64)
+    assert e.value.code == -1
+    path = make_scene(scene_dir, "cornell")
+    doc = json.load(open(path))
+    del doc["bufferViews"][0]["byteOffset"]            # undefined behaviour in the reference; an error here
+    p2 = os.path.join(scene_dir, "cornell_nobo.gltf")
+    json.dump(doc, open(p2, "w"))
+    os.replace(os.path.join(scene_dir, "cornell.bin"), os.path.join(scene_dir, "cornell.bin"))
+    with pytest.raises(rt.RtError) as e:
+        rt.load_gltf(p2, 64, 64)
+    assert "byteOffset" in str(e.value)
+    doc = json.load(open(path))
+    doc["accessors"][0]["componentType"] = 5121        # u8 indices are not supported (main.cpp:1077)
+    p3 = os.path.join(scene_dir, "cornell_u8.gltf")
+    json.dump(doc, open(p3, "w"))
+    with pytest.raises(rt.RtError) as e:
+        rt.load_gltf(p3, 64, 64)
+    assert "5123 or 5125" in str(e.value)
+    with pytest.raises(rt.RtError):
+        rt.load_gltf(path, 0, 64)
+
+
+def _check_flat(flat, tri_verts, tri_material, materials):
+    nodes, tris = flat["nodes"], flat["tris"]
+    n = tri_verts.shape[0]
+    ids = tris[:, 12].view(np.uint32)
+    assert sorted(ids.tolist()) == list(range(n))                      # a permutation of the loader order
+    assert np.array_equal(tris[:, 0:3], tri_verts[ids, 0])             # A
+    assert np.array_equal(tris[:, 3:6], tri_verts[ids, 1] - tri_verts[ids, 0])   # AB
+    assert np.array_equal(tris[:, 6:9], tri_verts[ids, 2] - tri_verts[ids, 0])   # AC
+    assert np.array_equal(tris[:, 13].view(np.uint32), tri_material[ids])
+    refs = nodes[:, 12:14].view(np.int32)
+    boxes = np.stack([nodes[:, 0:6], nodes[:, 6:12]], axis=1)           # (nn, 2, 6): lo xyz, hi xyz
+    tmin = tri_verts.min(axis=1)
+    tmax = tri_verts.max(axis=1)
+    seen = np.zeros(n, dtype=np.int32)
+    visited = np.zeros(nodes.shape[0], dtype=np.int32)
+
+    def walk(node, lo, hi, level):
+        visited[node] += 1
+        h = level
+        for side in range(2):
+            ref, b = refs[node, side], boxes[node, side]
+            if b[0] > 1e29:
+                continue                                               # absent child
+            if lo is not None:
+                assert (b[:3] >= lo - 1e-4).all() and (b[3:] <= hi + 1e-4).all()
+            if ref < 0:
+                r = ~int(ref)
+                first, cnt = r >> 3, (r & 7) + 1
+                assert cnt <= 4
+                for k in range(first, first + cnt):
+                    seen[k] += 1
+                    assert (tmin[ids[k]] >= b[:3]).all() and (tmax[ids[k]] <= b[3:]).all()
+            else:
+                h = max(h, walk(int(ref), b[:3], b[3:], level + 1))
+        return h
+
+    height = walk(0, None, None, 1)
+    assert (seen == 1).all() and (visited == 1).all()
+    assert height == flat["height"] <= 24
+    em = np.linalg.norm(materials["emission"][tri_material], axis=1) > 1e-4
+    assert np.array_equal(ids[flat["lights"]], np.flatnonzero(em))     # loader order, leaf positions
+
+
+@pytest.mark.parametrize("name,kw", [("cornell", {}), ("heightfield100k", {"nx": 40, "nz": 40}),
+                                     ("spheres1m", {"n_spheres": 10, "subdiv": 2, "ground": 8})])
+def test_flat_bvh_is_valid(scene_dir, name, kw):
+    import sys
+    import raytracing_amd as rt
+    sys.setrecursionlimit(10000)
+    host = rt.load_gltf(make_scene(scene_dir, name, **kw), 64, 64)
+    _check_flat(rt.build_flat(host), host.tri_verts, host.tri_material, host.materials)
+
+
+def test_flat_bvh_degenerate_inputs():
+    import raytracing_amd as rt
+    mats = np.zeros(1, dtype=rt.api.MATERIAL_DTYPE)
+    cam = dict(position=[0, 0, 0], right=[1, 0, 0], up=[0, 1, 0], forward=[0, 0, -1], tan_x=1, tan_y=1)
+    empty = rt.HostScene(np.zeros((0, 3, 3), np.float32), np.zeros(0, np.uint32), mats, cam)
+    f = rt.build_flat(empty)
+    assert f["nodes"].shape == (1, 16) and f["tris"].shape[0] == 0
+    # 3000 copies of the same triangle: no SAH split exists, the builder must still terminate and bound the height
+    tri = np.tile(np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], np.float32), (3000, 1, 1))
+    same = rt.HostScene(tri, np.zeros(3000, np.uint32), mats, cam)
+    _check_flat(rt.build_flat(same), same.tri_verts, same.tri_material, same.materials)
+    bad = rt.HostScene(tri[:2], np.array([0, 7], np.uint32), mats, cam)
+    with pytest.raises(rt.RtError):
+        rt.build_flat(bad)
+    nan = tri[:2].copy()
+    nan[0, 0, 0] = np.nan
+    with pytest.raises(rt.RtError):
+        rt.build_flat(rt.HostScene(nan, np.zeros(2, np.uint32), mats, cam))
+
+
+def test_ppm_writer(tmp_path):
+    """printImage (main.cpp:856-864): "P6\\nW H\\n255\\n" + RGB bytes."""
+    import raytracing_amd as rt
+    rgb = (np.arange(5 * 3 * 3) % 256).astype(np.uint8).reshape(-1, 3)
+    out = tmp_path / "x.ppm"
+    rt.print_image(rt.SceneFloat(5, 3, None, rgb), str(out))
+    data = out.read_bytes()
+    assert data.startswith(b"P6\n5 3\n255\n") and data[len(b"P6\n5 3\n255\n"):] == rgb.tobytes()
+    with pytest.raises(rt.RtError):
+        rt.print_image(rt.SceneFloat(5, 3, None, rgb), str(tmp_path / "no_dir" / "x.ppm"))
+
+
+def test_counter_seed_matches_oracle(oracle_mod):
+    import raytracing_amd as rt
+    rng = np.random.RandomState(1)
+    for p, s, sd in rng.randint(0, 2 ** 31, size=(200, 3)):
+        assert rt.counter_seed(int(p), int(s), int(sd)) == oracle_mod.counter_seed(int(p), int(s), int(sd))
+
+
+def test_sample_range_partition():
+    from raytracing_amd.dist import sample_range
+    for total in (0, 1, 7, 128, 1024, 4097):
+        for world in (1, 2, 3, 8):
+            parts = [sample_range(total, world, r) for r in range(world)]
+            assert parts[0][0] == 0 and sum(c for _, c in parts) == total
+            for (b0, c0), (b1, _) in zip(parts, parts[1:]):
+                assert b0 + c0 == b1
+            assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+    with pytest.raises(ValueError):
+        sample_range(8, 2, 2)
+
+
+def test_cli_usage_and_gpu_requirement(scene_dir):
+    exe = os.path.join(ROOT, "raytracing_amd", "bin", "raytracing")
+    assert os.path.exists(exe), "build the host with make -C raytracing_amd/csrc"
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+    r = subprocess.run([exe, make_scene(scene_dir, "cornell"), "0", "10", "1", "/tmp/x.ppm"], capture_output=True, text=True)
+    assert r.returncode == 2
+    import raytracing_amd as rt
+    if rt.device_count() == 0:  # no silent CPU fallback: without a GPU the host must fail loudly
+        r = subprocess.run([exe, make_scene(scene_dir, "cornell"), "32", "24", "1", os.path.join(scene_dir, "o.ppm")],
+                           capture_output=True, text=True)
+        assert r.returncode != 0 and "no HIP device" in r.stderr
+        with pytest.raises(rt.RtError) as e:
+            rt.Scene(rt.load_gltf(make_scene(scene_dir, "cornell"), 32, 24))
+        assert e.value.code == -3
