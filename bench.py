@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="spheres1m", choices=sorted(WORKLOADS))
-    ap.add_argument("--pipeline", default="mega", choices=["mega", "wavefront"])
+    ap.add_argument("--pipeline", default="wavefront", choices=["mega", "wavefront"])
     ap.add_argument("--spp-per-gpu", type=int, default=0, help="override the workload's samples per pixel per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-primary", action="store_true")
@@ -81,16 +81,10 @@ def main():
     stream = torch.cuda.current_stream()
     buf = torch.empty(npix * 3, dtype=torch.float32, device=dev)
     rgb = torch.empty(npix * 3, dtype=torch.uint8, device=dev)
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
     def step(k=None):
-        if k is not None:
-            ev0[k].record(stream)
         scene.render_dev(W, H, spp_gpu, buf.data_ptr(), max_depth=depth, rng_mode=rt.RNG_COUNTER, seed=seed,
                          spp_begin=rank * spp_gpu, pipeline=pipeline, stream=stream)
-        if k is not None:
-            ev1[k].record(stream)
         if world > 1:
             dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM)
         if rank == 0:
@@ -105,6 +99,7 @@ def main():
         step()
     barrier()
     scene.reset_counters(stream)
+    scene.set_timing(True)  # HIP events around every kernel, on the launch stream
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -113,7 +108,8 @@ def main():
     elapsed = time.perf_counter() - t0
 
     segs = scene.counters()["segments"]
-    kern_ms = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
+    ktimes = scene.kernel_times()
+    scene.set_timing(False)
     t = torch.tensor([elapsed, float(segs)], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = t.clone()
@@ -129,11 +125,15 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (this rank's render launch) ----------------------------
-    # Algorithmic bytes per ray segment: 64 B per BVH node visited (both child boxes), 48 B per
-    # ray/triangle test, 32 B for the winning triangle's shading record, 64 B per light-pdf triangle
-    # test; per pixel 12 B of output.  Visit counts come from the counting build of the same kernel
-    # on the same workload (one extra launch, outside the timed region).
+    # ---- roofline of the dominant kernel -----------------------------------------------------------
+    # Dominant kernel: wf_extend (closest hit of a ray queue) for the wavefront pipeline, k_render_mega
+    # for the megakernel.  Algorithmic bytes per ray segment: 64 B per BVH node visited (one node holds
+    # both child boxes), 48 B per ray/triangle test, plus per segment 36 B of queue traffic in the
+    # wavefront kernel (24 B ray + 4 B queue index read, 8 B hit written); the megakernel instead reads
+    # the 32 B shading record of the hit triangle and 64 B per light-pdf triangle test.  Visit counts
+    # come from the counting build of the same kernels on the same workload (one extra launch outside
+    # the timed region).  Duration: HIP events recorded around every launch of that kernel on its
+    # stream during the timed steps.
     scene.set_counting(True)
     scene.reset_counters(stream)
     count_spp = min(spp_gpu, 4)
@@ -145,17 +145,29 @@ def main():
     n_tri = c["tri_tests"] / c["segments"]
     n_light = c["light_tests"] / c["segments"]
     seg_per_sample = c["segments"] / float(npix * count_spp)
-    state_bytes = 0.0 if pipeline == rt.PIPE_MEGAKERNEL else 2 * (24 + 12 + 12 + 8) + 8 + 8
-    bytes_per_seg = 64.0 * n_node + 48.0 * n_tri + 32.0 + 64.0 * n_light + state_bytes
-    segs_per_launch = segs / float(args.steps)
-    launch_ms = sum(kern_ms) / len(kern_ms)
-    achieved = (segs_per_launch * bytes_per_seg + 12.0 * npix) / (launch_ms * 1e-3) / 1e9
+    if pipeline == rt.PIPE_MEGAKERNEL:
+        kname, kind = "k_render_mega", "mega"
+        bytes_per_seg = 64.0 * n_node + 48.0 * n_tri + 32.0 + 64.0 * n_light
+    else:
+        kname, kind = "wf_extend", "extend"
+        bytes_per_seg = 64.0 * n_node + 48.0 * n_tri + 36.0
+    k_ms, k_launches = ktimes[kind]
+    launch_ms = k_ms / max(k_launches, 1)
+    segs_per_launch = segs / float(max(k_launches, 1))
+    achieved = segs_per_launch * bytes_per_seg / (launch_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):  # HBM-side bytes per launch from the committed rocprofv3 --pmc passes
+        rec = json.load(open(tpath)).get("%s/%s" % (args.workload, kname))
+        if rec:
+            traffic = rec["bytes_per_launch"]
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "kernel": "k_render_mega" if pipeline == rt.PIPE_MEGAKERNEL else "wf_extend+wf_shade",
-                "launch_ms": round(launch_ms, 3), "bytes_per_segment": round(bytes_per_seg, 1),
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "kernel": kname, "launch_ms": round(launch_ms, 4), "launches": k_launches,
+                "segments_per_launch": round(segs_per_launch, 1), "bytes_per_segment": round(bytes_per_seg, 1),
                 "nodes_per_segment": round(n_node, 2), "tri_tests_per_segment": round(n_tri, 2),
-                "light_tests_per_segment": round(n_light, 2), "segments_per_sample": round(seg_per_sample, 3)}
+                "light_tests_per_segment": round(n_light, 2), "segments_per_sample": round(seg_per_sample, 3),
+                "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in ktimes.items() if v[1]}}
 
     # ---- primary-ray closest hit on the 100k-triangle mesh (informational) ----------------------
     extra = {}

@@ -183,6 +183,25 @@ int rt_set_counting(rt_scene *s, int enable); /* 1: launches also count nodes / 
 int rt_counters_reset(rt_scene *s, void *stream);
 int rt_counters_read(rt_scene *s, rt_counters *out); /* synchronises the device */
 
+/* ---- per-kernel device time (HIP events on the launch stream) ----
+ * rt_set_timing(s, 1) synchronises, clears the totals and makes every later launch record an event
+ * pair around each kernel; rt_timing_read synchronises and returns, per kernel kind, the summed
+ * device milliseconds and the number of launches since then. */
+#define RT_KERNEL_EXTEND 0      /* wavefront: closest hit of a ray queue */
+#define RT_KERNEL_SHADE 1       /* wavefront: shading + queue compaction */
+#define RT_KERNEL_GENERATE 2    /* wavefront: camera rays */
+#define RT_KERNEL_ACCUMULATE 3  /* wavefront: per-pixel sum of the finished samples */
+#define RT_KERNEL_MEGA 4        /* megakernel render */
+#define RT_KERNEL_CLOSEST_HIT 5 /* rt_trace_primary* / rt_intersect_rays* */
+#define RT_KERNEL_TONEMAP 6
+#define RT_KERNEL_KINDS 7
+typedef struct rt_kernel_times {
+    double ms[RT_KERNEL_KINDS];
+    uint64_t launches[RT_KERNEL_KINDS];
+} rt_kernel_times;
+int rt_set_timing(rt_scene *s, int enable);
+int rt_timing_read(rt_scene *s, rt_kernel_times *out);
+
 /* The seed of the per-(pixel, sample) stream of RT_RNG_COUNTER (host helper for checkers). */
 uint32_t rt_counter_seed(uint32_t pixel, uint32_t sample, uint32_t seed);
 

@@ -41,6 +41,13 @@ class Counters(C.Structure):
                 ("light_tests", C.c_uint64)]
 
 
+KERNEL_KINDS = ("extend", "shade", "generate", "accumulate", "mega", "closest_hit", "tonemap")
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [("ms", C.c_double * 7), ("launches", C.c_uint64 * 7)]
+
+
 # name -> (restype, argtypes); exactly the entry points of include/rt_amd.h
 SIGNATURES = {
     "rt_last_error": (C.c_char_p, []),
@@ -71,6 +78,8 @@ SIGNATURES = {
     "rt_set_counting": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_counters_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_counters_read": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
+    "rt_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_timing_read": (C.c_int, [C.c_void_p, C.POINTER(KernelTimes)]),
     "rt_counter_seed": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
 }
 

@@ -157,6 +157,16 @@ class Scene:
         return dict(segments=int(c.segments), nodes=int(c.nodes), tri_tests=int(c.tri_tests),
                     light_tests=int(c.light_tests))
 
+    def set_timing(self, enable):
+        """Record HIP events around every kernel of later launches (clears the totals)."""
+        check(_lib.lib().rt_set_timing(self._h, int(bool(enable))))
+
+    def kernel_times(self):
+        """{kind: (device ms summed over launches, launches)} since set_timing(True)."""
+        t = _lib.KernelTimes()
+        check(_lib.lib().rt_timing_read(self._h, C.byref(t)))
+        return {k: (float(t.ms[i]), int(t.launches[i])) for i, k in enumerate(_lib.KERNEL_KINDS)}
+
     # -- closest hit (intersectScene, main.cpp:1113) -----------------------------------------
     def intersect(self, origins, directions):
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)

@@ -30,6 +30,7 @@ struct rt_scene {
     uint64_t device_bytes = 0;
     bool counting = false;
     uint32_t nmat = 0;
+    rt::KernelTimer timer;
     uint64_t host_segments = 0;  // segments of launches whose ray count the host knows (one per ray)
 };
 
@@ -218,6 +219,7 @@ void rt_scene_destroy(rt_scene *s) {
     if (!s) return;
     DeviceGuard g(s->device);
     free_wavefront(s);
+    s->timer.release();
     (void)hipFree(s->d_nodes);
     (void)hipFree(s->d_tris);
     (void)hipFree(s->d_lights);
@@ -251,7 +253,7 @@ int rt_intersect_rays_dev(rt_scene *s, uint64_t n, const float *d_origins, const
     if (!d_origins || !d_directions || !d_prim_id || !d_t) return fail(RT_ERR_INVALID, "rt_intersect_rays_dev: null buffer");
     if (n > (1ull << 31)) return fail(RT_ERR_LIMIT, "rt_intersect_rays_dev: more than 2^31 rays in one call");
     DeviceGuard g(s->device);
-    RT_HIP(rt::launch_intersect(s->view, n, d_origins, d_directions, d_prim_id, d_t, s->counting, (hipStream_t)stream));
+    RT_HIP(rt::launch_intersect(s->view, n, d_origins, d_directions, d_prim_id, d_t, s->counting, (hipStream_t)stream, s->timer));
     s->host_segments += n;
     return RT_OK;
 }
@@ -288,7 +290,7 @@ int rt_trace_primary_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t 
     int rc = check_image(width, height);
     if (rc != RT_OK) return rc;
     DeviceGuard g(s->device);
-    RT_HIP(rt::launch_primary(s->view, width, height, d_prim_id, d_t, s->counting, (hipStream_t)stream));
+    RT_HIP(rt::launch_primary(s->view, width, height, d_prim_id, d_t, s->counting, (hipStream_t)stream, s->timer));
     s->host_segments += (uint64_t)width * height;
     return RT_OK;
 }
@@ -330,11 +332,11 @@ int rt_render_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_beg
     DeviceGuard g(s->device);
     rt::RenderParams rp{width, height, spp_begin, spp_count, max_depth, rng_mode, seed};
     if (pipeline == RT_PIPE_MEGAKERNEL) {
-        RT_HIP(rt::launch_render_mega(s->view, rp, d_radiance_sum, s->counting, (hipStream_t)stream));
+        RT_HIP(rt::launch_render_mega(s->view, rp, d_radiance_sum, s->counting, (hipStream_t)stream, s->timer));
     } else {
         rc = ensure_wavefront(s, width * height);
         if (rc != RT_OK) return rc;
-        RT_HIP(rt::launch_render_wavefront(s->view, rp, d_radiance_sum, s->wf, s->counting, (hipStream_t)stream));
+        RT_HIP(rt::launch_render_wavefront(s->view, rp, d_radiance_sum, s->wf, s->counting, (hipStream_t)stream, s->timer));
     }
     return RT_OK;
 }
@@ -361,7 +363,7 @@ int rt_tonemap_dev(rt_scene *s, const float *d_radiance_sum, uint64_t npixels, u
     if (!s || !d_radiance_sum) return fail(RT_ERR_INVALID, "rt_tonemap_dev: null argument");
     if (spp == 0) return fail(RT_ERR_INVALID, "rt_tonemap_dev: spp must be positive");
     DeviceGuard g(s->device);
-    RT_HIP(rt::launch_tonemap(d_radiance_sum, npixels, spp, d_out_float, d_out_rgb, (hipStream_t)stream));
+    RT_HIP(rt::launch_tonemap(d_radiance_sum, npixels, spp, d_out_float, d_out_rgb, (hipStream_t)stream, s->timer));
     return RT_OK;
 }
 
@@ -405,6 +407,27 @@ int rt_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_
 int rt_set_counting(rt_scene *s, int enable) {
     if (!s) return fail(RT_ERR_INVALID, "rt_set_counting: null scene");
     s->counting = enable != 0;
+    return RT_OK;
+}
+
+int rt_set_timing(rt_scene *s, int enable) {
+    if (!s) return fail(RT_ERR_INVALID, "rt_set_timing: null scene");
+    DeviceGuard g(s->device);
+    RT_HIP(hipDeviceSynchronize());
+    s->timer.reset();
+    s->timer.enabled = enable != 0;
+    return RT_OK;
+}
+
+int rt_timing_read(rt_scene *s, rt_kernel_times *out) {
+    if (!s || !out) return fail(RT_ERR_INVALID, "rt_timing_read: null argument");
+    DeviceGuard g(s->device);
+    RT_HIP(hipDeviceSynchronize());
+    s->timer.collect();
+    for (int k = 0; k < RT_KERNEL_KINDS; ++k) {
+        out->ms[k] = s->timer.ms[k];
+        out->launches[k] = s->timer.launches[k];
+    }
     return RT_OK;
 }
 

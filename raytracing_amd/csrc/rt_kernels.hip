@@ -341,32 +341,38 @@ constexpr uint32_t kExtendBlocks = 256u * 6u;      // 256 CUs x 6 resident workg
 namespace rt {
 
 hipError_t launch_intersect(const DevScene &S, uint64_t n, const float *o, const float *d, uint32_t *prim_id, float *t,
-                            bool count, hipStream_t stream) {
+                            bool count, hipStream_t stream, KernelTimer &timer) {
     if (n == 0) return hipSuccess;
     const uint32_t grid = (uint32_t)((n + kBlock - 1) / kBlock);
+    timer.begin(kKernClosestHit, stream);
     if (count) hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(kBlock), 0, stream, S, n, o, d, prim_id, t);
     else hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(kBlock), 0, stream, S, n, o, d, prim_id, t);
+    timer.end(stream);
     return hipGetLastError();
 }
 
 hipError_t launch_primary(const DevScene &S, uint32_t W, uint32_t H, uint32_t *prim_id, float *t, bool count,
-                          hipStream_t stream) {
+                          hipStream_t stream, KernelTimer &timer) {
     const uint32_t grid = pixel_grid(W, H);
+    timer.begin(kKernClosestHit, stream);
     if (count) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), 0, stream, S, W, H, prim_id, t);
     else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), 0, stream, S, W, H, prim_id, t);
+    timer.end(stream);
     return hipGetLastError();
 }
 
 hipError_t launch_render_mega(const DevScene &S, const RenderParams &rp, float *radiance_sum, bool count,
-                              hipStream_t stream) {
+                              hipStream_t stream, KernelTimer &timer) {
     const uint32_t grid = pixel_grid(rp.W, rp.H);
+    timer.begin(kKernMega, stream);
     if (count) hipLaunchKernelGGL(k_render_mega<true>, dim3(grid), dim3(kBlock), 0, stream, S, rp, radiance_sum);
     else hipLaunchKernelGGL(k_render_mega<false>, dim3(grid), dim3(kBlock), 0, stream, S, rp, radiance_sum);
+    timer.end(stream);
     return hipGetLastError();
 }
 
 hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, float *radiance_sum,
-                                   const WavefrontBuffers &wb, bool count, hipStream_t stream) {
+                                   const WavefrontBuffers &wb, bool count, hipStream_t stream, KernelTimer &timer) {
     const uint32_t npix = rp.W * rp.H;
     const uint32_t slots = wb.capacity / npix;  // samples in flight per pass (host guarantees >= 1)
     WfView V{wb.ray, wb.thr, wb.rad, wb.rng, wb.meta, wb.hit_t, wb.hit_tri, wb.capacity};
@@ -379,24 +385,32 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
                                                                                  : kPersistentBlocks;
         // extend runs persistent waves: as many workgroups as stay resident
         const uint32_t egrid = grid < kExtendBlocks ? grid : kExtendBlocks;
+        timer.begin(kKernGenerate, stream);
         hipLaunchKernelGGL(wf_generate, dim3(grid), dim3(kBlock), 0, stream, S, rp, V, npaths, rp.spp_begin + done,
                            wb.qcount);
+        timer.end(stream);
         const uint32_t bounces = rp.max_depth ? rp.max_depth : 1u;  // depth 0 still traces the camera ray
         for (uint32_t b = 0; b < bounces; ++b) {
             const uint32_t in = b & 1u, out = in ^ 1u;
             const uint32_t *qin = (b == 0) ? nullptr : wb.queue[in];
+            timer.begin(kKernExtend, stream);
             if (count)
                 hipLaunchKernelGGL(wf_extend<true>, dim3(egrid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in,
                                    wb.qcount + out, wb.qcount + 2);
             else
                 hipLaunchKernelGGL(wf_extend<false>, dim3(egrid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in,
                                    wb.qcount + out, wb.qcount + 2);
+            timer.end(stream);
+            timer.begin(kKernShade, stream);
             hipLaunchKernelGGL(wf_shade, dim3(grid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in, wb.queue[out],
                                wb.qcount + out, wb.qcount + 2);
+            timer.end(stream);
         }
         const uint32_t agrid = (npix + kBlock - 1) / kBlock < kPersistentBlocks ? (npix + kBlock - 1) / kBlock
                                                                                 : kPersistentBlocks;
+        timer.begin(kKernAccumulate, stream);
         hipLaunchKernelGGL(wf_accumulate, dim3(agrid), dim3(kBlock), 0, stream, V, npix, ns, first ? 1 : 0, radiance_sum);
+        timer.end(stream);
         first = false;
         done += ns;
         hipError_t e = hipGetLastError();
@@ -407,13 +421,15 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
 }
 
 hipError_t launch_tonemap(const float *radiance_sum, uint64_t npixels, uint32_t spp, float *out_float, uint8_t *out_rgb,
-                          hipStream_t stream) {
+                          hipStream_t stream, KernelTimer &timer) {
     const uint64_t n3 = npixels * 3;
     if (n3 == 0) return hipSuccess;
     uint64_t grid = (n3 + kBlock - 1) / kBlock;
     if (grid > kPersistentBlocks) grid = kPersistentBlocks;
+    timer.begin(kKernTonemap, stream);
     hipLaunchKernelGGL(k_tonemap, dim3((uint32_t)grid), dim3(kBlock), 0, stream, radiance_sum, n3, (float)spp, out_float,
                        out_rgb);
+    timer.end(stream);
     return hipGetLastError();
 }
 

@@ -4,9 +4,72 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "rt_device.h"
 
 namespace rt {
+
+// Optional per-kernel timing with HIP events recorded on the launch stream (rt_set_timing).
+// Spans are collected after a synchronisation; disabled, begin/end cost nothing.
+enum KernelKind { kKernExtend = 0, kKernShade, kKernGenerate, kKernAccumulate, kKernMega, kKernClosestHit, kKernTonemap, kKernKinds };
+
+struct KernelTimer {
+    bool enabled = false;
+    std::vector<hipEvent_t> pool;
+    struct Span {
+        int kind;
+        hipEvent_t a, b;
+    };
+    std::vector<Span> spans;
+    double ms[kKernKinds] = {0};
+    unsigned long long launches[kKernKinds] = {0};
+
+    hipEvent_t get() {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void begin(int kind, hipStream_t stream) {
+        if (!enabled) return;
+        Span s{kind, get(), get()};
+        (void)hipEventRecord(s.a, stream);
+        spans.push_back(s);
+    }
+    void end(hipStream_t stream) {
+        if (!enabled || spans.empty()) return;
+        (void)hipEventRecord(spans.back().b, stream);
+    }
+    void collect() {  // caller has synchronised the device
+        for (const Span &s : spans) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, s.a, s.b) == hipSuccess) {
+                ms[s.kind] += t;
+                ++launches[s.kind];
+            }
+            pool.push_back(s.a);
+            pool.push_back(s.b);
+        }
+        spans.clear();
+    }
+    void reset() {
+        collect();
+        for (int k = 0; k < kKernKinds; ++k) {
+            ms[k] = 0;
+            launches[k] = 0;
+        }
+    }
+    void release() {
+        collect();
+        for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+        pool.clear();
+    }
+};
 
 struct RenderParams {
     uint32_t W, H;
@@ -32,14 +95,14 @@ struct WavefrontBuffers {
 };
 
 hipError_t launch_intersect(const rtd::DevScene &S, uint64_t n, const float *o, const float *d, uint32_t *prim_id,
-                            float *t, bool count, hipStream_t stream);
+                            float *t, bool count, hipStream_t stream, KernelTimer &timer);
 hipError_t launch_primary(const rtd::DevScene &S, uint32_t W, uint32_t H, uint32_t *prim_id, float *t, bool count,
-                          hipStream_t stream);
+                          hipStream_t stream, KernelTimer &timer);
 hipError_t launch_render_mega(const rtd::DevScene &S, const RenderParams &rp, float *radiance_sum, bool count,
-                              hipStream_t stream);
+                              hipStream_t stream, KernelTimer &timer);
 hipError_t launch_render_wavefront(const rtd::DevScene &S, const RenderParams &rp, float *radiance_sum,
-                                   const WavefrontBuffers &wb, bool count, hipStream_t stream);
+                                   const WavefrontBuffers &wb, bool count, hipStream_t stream, KernelTimer &timer);
 hipError_t launch_tonemap(const float *radiance_sum, uint64_t npixels, uint32_t spp, float *out_float,
-                          uint8_t *out_rgb, hipStream_t stream);
+                          uint8_t *out_rgb, hipStream_t stream, KernelTimer &timer);
 
 }  // namespace rt
