@@ -157,13 +157,18 @@ __device__ __forceinline__ bool tri_test(float4 q0, float4 q1, float4 q2, v3 o, 
     return !(u < 0.f || v < 0.f || t < 0.f || u + v > 1.f);
 }
 
-// Conservative slab test against a padded box; NaNs from 0 * inf drop out of min/max, which
-// leaves that slab unconstrained (never a false miss).
-__device__ __forceinline__ bool box_test(float lox, float loy, float loz, float hix, float hiy, float hiz, v3 o,
-                                         v3 id, float tBest, float &tNear) {
-    const float ax = (lox - o.x) * id.x, bx = (hix - o.x) * id.x;
-    const float ay = (loy - o.y) * id.y, by = (hiy - o.y) * id.y;
-    const float az = (loz - o.z) * id.z, bz = (hiz - o.z) * id.z;
+// Conservative slab test against a padded box: plane distances as one FMA each,
+// t = plane * (1/d) - o * (1/d).  That rounds differently from (plane - o) / d, by at most a few
+// ulps of |o / d| in t, i.e. a few ulps of |o| in position -- far inside the padding the host put
+// on every box (1e-5 + 4e-7 |coordinate|).  The reciprocal direction is clamped to +-1e30 (see
+// Traversal::start) so that no inf - inf = NaN can arise for axis-parallel rays: a NaN on one plane
+// of a slab would silently turn min/max of the pair into the other plane's value, a false miss.
+// A NaN DIRECTION still makes every comparison fail: a miss, like the reference (main.cpp:1158).
+__device__ __forceinline__ bool box_test(float lox, float loy, float loz, float hix, float hiy, float hiz, v3 id,
+                                         v3 nob, float tBest, float &tNear) {
+    const float ax = __builtin_fmaf(lox, id.x, nob.x), bx = __builtin_fmaf(hix, id.x, nob.x);
+    const float ay = __builtin_fmaf(loy, id.y, nob.y), by = __builtin_fmaf(hiy, id.y, nob.y);
+    const float az = __builtin_fmaf(loz, id.z, nob.z), bz = __builtin_fmaf(hiz, id.z, nob.z);
     const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
                                      __builtin_fminf(az, bz));
     const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
@@ -191,7 +196,7 @@ constexpr int kSentinel = 0x7FFFFFFF;  // "stack is empty": never a node index, 
 
 template <bool COUNT>
 struct Traversal {
-    v3 o, d, id;
+    v3 o, d, id, nob;  // origin, direction, 1/d, -o/d
     float tBest;
     int triBest;
     int cur;   // >= 0 inner node to visit, < 0 leaf reference, kSentinel = nothing left
@@ -201,10 +206,18 @@ struct Traversal {
 
     // lane_stack: &lds[threadIdx.x]
     __device__ __forceinline__ void bind(int *lane_stack) { stack = lane_stack; }
+
+    // 1/v with |v| clamped to >= 1e-30: tilts an axis-parallel ray by less than any box padding over
+    // the scene's extent and keeps every plane distance finite
+    static __device__ __forceinline__ float recip_clamped(float v) {
+        if (__builtin_fabsf(v) < 1.0e-30f) v = __builtin_copysignf(1.0e-30f, v);
+        return 1.f / v;
+    }
     __device__ __forceinline__ void start(v3 ro, v3 rd) {
         o = ro;
         d = rd;
-        id = mk(1.f / rd.x, 1.f / rd.y, 1.f / rd.z);
+        id = mk(recip_clamped(rd.x), recip_clamped(rd.y), recip_clamped(rd.z));
+        nob = mk(-(ro.x * id.x), -(ro.y * id.y), -(ro.z * id.z));
         tBest = kInf;
         triBest = -1;
         cur = 0;
@@ -235,8 +248,8 @@ struct Traversal {
             const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
             if (COUNT) ++st.nodes;
             float tnL, tnR;
-            const bool hL = box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, o, id, tBest, tnL);
-            const bool hR = box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, o, id, tBest, tnR);
+            const bool hL = box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, id, nob, tBest, tnL);
+            const bool hR = box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, id, nob, tBest, tnR);
             const int cl = __float_as_int(n3.x), cr = __float_as_int(n3.y);
             if (hL && hR) {
                 const bool leftFirst = tnL <= tnR;
