@@ -62,8 +62,16 @@ def main():
         raise SystemExit("--gpus (%d) does not match WORLD_SIZE (%d)" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+    # RT_BENCH_FORCE_DIST=1 runs the collective path (RCCL init, reduce, barrier) even with one rank,
+    # to rehearse it on a single-GPU box.
+    use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(backend="nccl", device_id=dev, rank=0, world_size=1)
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     gen, gen_kw, W, H, spp_gpu, depth = WORKLOADS[args.workload]
     if args.spp_per_gpu > 0:
@@ -85,13 +93,13 @@ def main():
     def step(k=None):
         scene.render_dev(W, H, spp_gpu, buf.data_ptr(), max_depth=depth, rng_mode=rt.RNG_COUNTER, seed=seed,
                          spp_begin=rank * spp_gpu, pipeline=pipeline, stream=stream)
-        if world > 1:
+        if use_dist:
             dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM)
         if rank == 0:
             scene.tonemap_dev(buf.data_ptr(), npix, spp_gpu * world, out_rgb_ptr=rgb.data_ptr(), stream=stream)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -111,7 +119,7 @@ def main():
     ktimes = scene.kernel_times()
     scene.set_timing(False)
     t = torch.tensor([elapsed, float(segs)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -121,8 +129,7 @@ def main():
         total_segs = float(segs)
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     # ---- roofline of the dominant kernel -----------------------------------------------------------
@@ -225,7 +232,7 @@ def main():
     out.update(extra)
     print(json.dumps(out))
     scene.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
