@@ -187,8 +187,9 @@ __global__ __launch_bounds__(kBlock) void wf_generate(DevScene S, rt::RenderPara
 // Persistent waves with per-lane dynamic ray fetch: a lane whose ray has finished takes the next
 // ray of the queue instead of idling until the slowest lane of its wave is done.  A wave grabs
 // kChunk consecutive queue entries with one atomic on the work cursor and deals them to its idle
-// lanes (ballot + prefix count) whenever at least kRefill lanes are idle.
-constexpr uint32_t kChunk = 128;
+// lanes (ballot + prefix count) whenever at least kRefill lanes are idle.  kChunk is large because
+// the cursor is one word of global memory (about 88 atomics per microsecond for the whole chip).
+constexpr uint32_t kChunk = 512;
 constexpr int kRefill = 12;
 
 template <bool COUNT>
@@ -252,17 +253,29 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
     if (segs) add_counters(S, segs, st, 0u, COUNT);
 }
 
-// Shades the hits of the input queue and appends the surviving paths to the output queue:
-// one ballot per wave, one atomic per wave, lanes write at their prefix offset.
+// Shades the hits of the input queue and appends the surviving paths to the output queue.
+// Appending is hierarchical, because one word of global memory takes only about 88 atomic adds per
+// microsecond however many CUs issue them: with one global atomic per wave and round this kernel
+// (and through its work cursor, wf_extend) ran at exactly that rate -- 1.65 M atomics = 17 ms per
+// 16-spp pass of the 1080p Cornell frame.  Survivors are first collected in an LDS buffer of the
+// workgroup (one LDS atomic per wave and round, lanes write at their ballot-prefix offset); when the
+// buffer is nearly full, and after the last round, the workgroup reserves space in the global
+// queue with ONE atomic and copies the buffer out with coalesced stores.
+constexpr uint32_t kAppendBuf = 2048;  // LDS entries per workgroup (8 KB); flushed above kAppendBuf - kBlock
+
 __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const uint32_t *__restrict__ queue,
                                                     const uint32_t *__restrict__ qcount_in,
                                                     uint32_t *__restrict__ queue_out, uint32_t *__restrict__ qcount_out,
                                                     uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t s_buf[kAppendBuf];
+    __shared__ uint32_t s_count, s_base;
     const uint32_t count = *qcount_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) *cursor = 0u;  // work cursor of the next extend pass
+    if (threadIdx.x == 0) s_count = 0u;
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t lightTests = 0;
-    // every lane of a wave runs the same number of iterations so the ballot sees the whole wave
+    // every thread of the workgroup runs the same number of rounds: the barriers below are uniform
     const uint32_t stride = gridDim.x * kBlock;
     const uint32_t rounds = (count + stride - 1u) / stride;
     for (uint32_t r = 0; r < rounds; ++r) {
@@ -298,10 +311,22 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const u
         }
         const unsigned long long mask = __ballot(alive);
         if (mask) {
+            const int leader = __builtin_ctzll(mask);
             uint32_t base = 0;
-            if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(qcount_out, (uint32_t)__builtin_popcountll(mask));
-            base = __shfl(base, __builtin_ctzll(mask));
-            if (alive) queue_out[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = i;
+            if (lane == (uint32_t)leader) base = atomicAdd(&s_count, (uint32_t)__builtin_popcountll(mask));
+            base = __shfl(base, leader);
+            if (alive) s_buf[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = i;
+        }
+        __syncthreads();
+        const uint32_t n = s_count;
+        if (n > kAppendBuf - kBlock || (r + 1 == rounds && n)) {  // uniform: every thread read the same s_count
+            if (threadIdx.x == 0) s_base = atomicAdd(qcount_out, n);
+            __syncthreads();
+            const uint32_t gbase = s_base;
+            for (uint32_t k = threadIdx.x; k < n; k += kBlock) queue_out[gbase + k] = s_buf[k];
+            __syncthreads();
+            if (threadIdx.x == 0) s_count = 0u;
+            __syncthreads();
         }
     }
     if (lightTests) add_counters(S, 0u, TraceStats{0, 0}, lightTests, false);
