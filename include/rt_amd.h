@@ -115,6 +115,11 @@ typedef struct rt_counters {
     uint64_t nodes;
     uint64_t tri_tests;
     uint64_t light_tests;
+    /* counted launches only: lane slots the wave64s spent in the node phase / triangle phase of the
+     * traversal (iterations of the wave, summed over its 64 lanes); nodes / node_lane_slots is the
+     * fraction of those slots that did useful work */
+    uint64_t node_lane_slots;
+    uint64_t tri_lane_slots;
 } rt_counters;
 
 const char *rt_last_error(void);

@@ -38,7 +38,7 @@ class SceneStats(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("segments", C.c_uint64), ("nodes", C.c_uint64), ("tri_tests", C.c_uint64),
-                ("light_tests", C.c_uint64)]
+                ("light_tests", C.c_uint64), ("node_lane_slots", C.c_uint64), ("tri_lane_slots", C.c_uint64)]
 
 
 KERNEL_KINDS = ("extend", "shade", "generate", "accumulate", "mega", "closest_hit", "tonemap")

@@ -450,13 +450,15 @@ int rt_counters_read(rt_scene *s, rt_counters *out) {
     std::vector<unsigned long long> raw(kCounterWords);
     RT_HIP(hipDeviceSynchronize());
     RT_HIP(hipMemcpy(raw.data(), s->d_counters, kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    unsigned long long h[4] = {0, 0, 0, 0};
+    unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
     for (int sh = 0; sh < rtd::kCounterShards; ++sh)
-        for (int k = 0; k < 4; ++k) h[k] += raw[(size_t)sh * rtd::kCounterStride + k];
+        for (int k = 0; k < 6; ++k) h[k] += raw[(size_t)sh * rtd::kCounterStride + k];
     out->segments = h[0] + s->host_segments;
     out->nodes = h[1];
     out->tri_tests = h[2];
     out->light_tests = h[3];
+    out->node_lane_slots = h[4];
+    out->tri_lane_slots = h[5];
     return RT_OK;
 }
 

@@ -17,6 +17,7 @@ constexpr float kInf = 10000.f;    // INF, main.cpp:23
 constexpr float kOneOverPi = 0.318309886183790671537767526745028724f;  // glm::one_over_pi<float>()
 constexpr int kBlock = 256;        // threads per workgroup of every traversal kernel (4 waves)
 constexpr int kStack = 24;         // traversal stack entries per lane, all in LDS (host checks tree height)
+constexpr int kExitLanes = 12;     // wf_extend: node phase ends when this few walking lanes still lack a leaf
 constexpr int kCounterShards = 256;   // statistics counters: shards (power of two) ...
 constexpr int kCounterStride = 16;    // ... of 16 x u64 = one 128-byte line each
 
@@ -124,7 +125,19 @@ struct DevScene {
 
 struct TraceStats {
     uint32_t nodes, tris;
+    // lane occupancy of the two traversal phases (COUNT builds only): iterations this lane was active
+    // in, and iterations its wave ran (the maximum over the wave's lanes), summed over phases
+    uint32_t nodeWave, triWave;
 };
+
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, m);
+        v = v > o ? v : o;
+    }
+    return v;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Ray / triangle: uvt = inverse(mat3(AB, AC, -d)) * (o - A) evaluated exactly as glm does
@@ -194,7 +207,7 @@ __device__ __forceinline__ bool box_test(float lox, float loy, float loz, float 
 // height bound (kStack inner levels) is what keeps the stack from overflowing.
 constexpr int kSentinel = 0x7FFFFFFF;  // "stack is empty": never a node index, never a leaf reference
 
-template <bool COUNT>
+template <bool COUNT, int EXIT_LANES = 0>
 struct Traversal {
     v3 o, d, id, nob;  // origin, direction, 1/d, -o/d
     float tBest;
@@ -243,6 +256,7 @@ struct Traversal {
     // One round: walk inner nodes until this lane holds a leaf (or has nothing left), then test
     // the triangles of the leaves it holds.
     __device__ __forceinline__ void step(const DevScene &S, TraceStats &st) {
+        const uint32_t nodes0 = st.nodes, tris0 = st.tris;
         while (cur >= 0 && cur != kSentinel) {
             const float4 *np = S.nodes + 4 * (size_t)cur;
             const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
@@ -266,7 +280,12 @@ struct Traversal {
                 leaf = cur;
                 cur = pop();
             }
-            if (__all(leaf != 0)) break;  // every lane still walking already holds a leaf
+            // Leave the node phase once at most EXIT_LANES of the lanes still walking hold no leaf yet:
+            // for incoherent rays, waiting for the last few stragglers kept most of the wave idle (lane
+            // occupancy of this phase was 44 %); they simply resume after the triangle phase.  Queue
+            // tracing, million-triangle workload: 0 (= wait for all) 2445, 4: 2673, 12: 2681, 24: 2623
+            // Mrays/s.  Coherent camera rays and the megakernel lose 8-9 % with 12, so they use 0.
+            if (__builtin_popcountll(__ballot(leaf == 0)) <= EXIT_LANES) break;
         }
         while (leaf != 0) {
             const uint32_t ref = ~(uint32_t)leaf;
@@ -285,6 +304,10 @@ struct Traversal {
                 leaf = cur;
                 cur = pop();
             }
+        }
+        if (COUNT) {  // all lanes of the wave are converged here
+            st.nodeWave += wave_max(st.nodes - nodes0);
+            st.triWave += wave_max(st.tris - tris0);
         }
     }
 };

@@ -48,6 +48,8 @@ __device__ __forceinline__ void add_counters(const DevScene &S, uint32_t segs, c
     if (count) {
         atomicAdd(&c[1], (unsigned long long)st.nodes);
         atomicAdd(&c[2], (unsigned long long)st.tris);
+        atomicAdd(&c[4], (unsigned long long)st.nodeWave);
+        atomicAdd(&c[5], (unsigned long long)st.triWave);
     }
     if (lights) atomicAdd(&c[3], (unsigned long long)lights);
 }
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, uint64_t n, co
     const v3 rd = mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     float t;
     int tri;
-    TraceStats st{0, 0};
+    TraceStats st{0, 0, 0, 0};
     closest_hit<COUNT>(S, ro, rd, s_stack + threadIdx.x, t, tri, st);
     prim_id[i] = tri >= 0 ? tri_loader_id(S, tri) : 0xFFFFFFFFu;
     tout[i] = t;
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, uint32_t W, uint
     const v3 ro = mk(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]);
     float t;
     int tri;
-    TraceStats st{0, 0};
+    TraceStats st{0, 0, 0, 0};
     closest_hit<COUNT>(S, ro, rd, s_stack + threadIdx.x, t, tri, st);
     prim_id[pix] = tri >= 0 ? tri_loader_id(S, tri) : 0xFFFFFFFFu;
     tout[pix] = t;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void k_render_mega(DevScene S, rt::RenderPa
     v3 acc = mk(0.f, 0.f, 0.f);
     uint32_t s = 0, segs = 0, lightTests = 0;
     bool active = false;
-    TraceStats st{0, 0};
+    TraceStats st{0, 0, 0, 0};
     for (;;) {
         if (!active) {
             if (s >= rp.spp_count) break;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void wf_generate(DevScene S, rt::RenderPara
 // lanes (ballot + prefix count) whenever at least kRefill lanes are idle.  kChunk is large because
 // the cursor is one word of global memory (about 88 atomics per microsecond for the whole chip).
 constexpr uint32_t kChunk = 512;
-constexpr int kRefill = 12;
+constexpr int kRefill = 12;  // insensitive: 4 / 12 / 24 / 32 idle lanes all within 1 %
 
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const uint32_t *__restrict__ queue,
@@ -200,14 +202,14 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
     const uint32_t count = *qcount_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) *qcount_zero = 0u;  // the queue the next shade pass fills
     const uint32_t lane = threadIdx.x & 63u;
-    Traversal<COUNT> T;
+    Traversal<COUNT, kExitLanes> T;
     T.idle();
     T.bind(s_stack + threadIdx.x);
     uint32_t slot = 0, segs = 0;
     bool hasRay = false;
     uint32_t chunkNext = 0, chunkEnd = 0;  // wave-uniform
     bool exhausted = false;                // wave-uniform: the cursor ran past the queue
-    TraceStats st{0, 0};
+    TraceStats st{0, 0, 0, 0};
     for (;;) {
         if (hasRay && T.done()) {
             V.hit_t[slot] = T.tBest;
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const u
             __syncthreads();
         }
     }
-    if (lightTests) add_counters(S, 0u, TraceStats{0, 0}, lightTests, false);
+    if (lightTests) add_counters(S, 0u, TraceStats{0, 0, 0, 0}, lightTests, false);
 }
 
 // radiance_sum[pix] (+)= sum over the batch's sample slots, in slot order (deterministic).
