@@ -174,6 +174,10 @@ def main():
                 "segments_per_launch": round(segs_per_launch, 1), "bytes_per_segment": round(bytes_per_seg, 1),
                 "nodes_per_segment": round(n_node, 2), "tri_tests_per_segment": round(n_tri, 2),
                 "light_tests_per_segment": round(n_light, 2), "segments_per_sample": round(seg_per_sample, 3),
+                "lane_occupancy": {"node_phase": round(c["nodes"] / max(c["node_lane_slots"], 1), 3),
+                                   "triangle_phase": round(c["tri_tests"] / max(c["tri_lane_slots"], 1), 3)},
+                "note": "algorithmic bytes are served mostly by L1/L2/Infinity Cache (the scene fits on chip), so "
+                        "achieved can exceed the HBM peak; traffic = measured fabric bytes per launch (rocprofv3 PMC)",
                 "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in ktimes.items() if v[1]}}
 
     # ---- primary-ray closest hit on the 100k-triangle mesh (informational) ----------------------

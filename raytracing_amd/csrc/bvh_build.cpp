@@ -4,8 +4,8 @@
 // on three fully sorted axes per node, with sweep buffers sized by the whole scene (O(N^2)),
 // and uses 16-bit ids.  The closest hit does not depend on the tree's shape (apart from exact
 // distance ties), so this builder is free to differ: 32-bin SAH on triangle centroids,
-// O(N log N), subtrees built as OpenMP tasks, 32-bit ids, leaves of at most 4 triangles like
-// the reference (main.cpp:618), and a bounded height so that the kernels' fixed per-lane stack
+// O(N log N), subtrees built as OpenMP tasks, 32-bit ids, leaves of at most 2 triangles (the
+// reference uses 4, main.cpp:618), and a bounded height so that the kernels' fixed per-lane stack
 // can never overflow.  Per-triangle derived data follows Triangle::update (main.cpp:527-536).
 #include <algorithm>
 #include <atomic>

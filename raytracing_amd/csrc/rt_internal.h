@@ -18,7 +18,7 @@ struct rt_host_scene {
 namespace rt {
 
 // Traversal limits the kernels are built for; checked on the host before any launch.
-constexpr uint32_t kMaxLeafTris = 4;     // the reference's leaf size (main.cpp:618)
+constexpr uint32_t kMaxLeafTris = 2;     // reference: 4 (main.cpp:618); a lane slot of the triangle phase costs ~2.3 node slots, and 2 measured +2 %
 constexpr uint32_t kStackEntries = 24;   // per-lane traversal stack held in LDS
 constexpr uint32_t kMaxTreeHeight = 24;  // builder guarantee: pending stack entries <= height
 constexpr uint32_t kMaxTriangles = 1u << 28;

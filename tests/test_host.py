@@ -145,7 +145,7 @@ def _check_flat(flat, tri_verts, tri_material, materials):
             if ref < 0:
                 r = ~int(ref)
                 first, cnt = r >> 3, (r & 7) + 1
-                assert cnt <= 4
+                assert cnt <= 2
                 for k in range(first, first + cnt):
                     seen[k] += 1
                     assert (tmin[ids[k]] >= b[:3]).all() and (tmax[ids[k]] <= b[3:]).all()
