@@ -47,7 +47,10 @@ extern "C" {
 
 /* RNG modes of rt_render*.
  * RT_RNG_REFERENCE reproduces main.cpp:1221-1225: one minstd_rand per pixel seeded with
- * py*W+px, carried across that pixel's samples (so spp_begin must be 0).
+ * py*W+px, carried across that pixel's samples (so spp_begin must be 0).  It also evaluates each
+ * sample in the reference's recursion order (innermost bounce first), so the radiance sums equal the
+ * CPU path's bit for bit; it is the validation mode (max_depth <= 64, allocates its record buffer on
+ * first use), not the fast one.
  * RT_RNG_COUNTER seeds a fresh minstd_rand per (pixel, sample) from a hash of
  * (pixel, sample, seed); any sample range can then be rendered on any GPU. */
 #define RT_RNG_REFERENCE 0

@@ -28,6 +28,8 @@ struct rt_scene {
     rtd::DevMaterial *d_mats = nullptr;
     unsigned long long *d_counters = nullptr;
     rt::WavefrontBuffers wf;
+    uint32_t *d_replay = nullptr;  // vertex records of the replay kernel, grown to the largest request
+    uint64_t replay_words = 0;
     uint64_t device_bytes = 0;
     bool counting = false;
     uint32_t nmat = 0;
@@ -224,6 +226,7 @@ void rt_scene_destroy(rt_scene *s) {
     if (!s) return;
     DeviceGuard g(s->device);
     free_wavefront(s);
+    (void)hipFree(s->d_replay);
     s->timer.release();
     (void)hipFree(s->d_nodes);
     (void)hipFree(s->d_tris);
@@ -336,7 +339,21 @@ int rt_render_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_beg
     if ((uint64_t)spp_begin + spp_count > 0xFFFFFFFFull) return fail(RT_ERR_LIMIT, "rt_render_dev: sample range overflows 32 bits");
     DeviceGuard g(s->device);
     rt::RenderParams rp{width, height, spp_begin, spp_count, max_depth, rng_mode, seed};
-    if (pipeline == RT_PIPE_MEGAKERNEL) {
+    if (pipeline == RT_PIPE_MEGAKERNEL && rng_mode == RT_RNG_REFERENCE) {
+        // the reference's stream in the reference's evaluation order (bit-exact validation path)
+        if (max_depth > 64) return fail(RT_ERR_LIMIT, "rt_render_dev: RT_RNG_REFERENCE supports max_depth <= 64");
+        const uint64_t words = rt::replay_words(rp);
+        if (words > s->replay_words) {
+            RT_HIP(hipDeviceSynchronize());
+            (void)hipFree(s->d_replay);
+            s->d_replay = nullptr;
+            s->device_bytes -= s->replay_words * 4;
+            s->replay_words = 0;
+            RT_HIP(dev_alloc(s, &s->d_replay, (size_t)words));
+            s->replay_words = words;
+        }
+        RT_HIP(rt::launch_render_replay(s->view, rp, d_radiance_sum, s->d_replay, s->counting, (hipStream_t)stream, s->timer));
+    } else if (pipeline == RT_PIPE_MEGAKERNEL) {
         RT_HIP(rt::launch_render_mega(s->view, rp, d_radiance_sum, s->counting, (hipStream_t)stream, s->timer));
     } else {
         rc = ensure_wavefront(s, width * height);

@@ -71,8 +71,39 @@ __device__ __forceinline__ uint32_t rng_uint(uint32_t &x, uint32_t L) {
     return r / scaling;
 }
 
-// Natural logarithm of a float in (0, 1] for the polar method below (std::log(float)).
-__device__ __forceinline__ float rng_logf(float v) { return __builtin_logf(v); }
+// Natural logarithm of a normal float for the polar method below.  The reference calls
+// std::log(float) = glibc's logf, whose published algorithm (a 16-entry table of 1/c and log c, a
+// degree-3 polynomial, all in double, one final rounding to float) is restated here so that the
+// Gaussian samples -- and with them every later branch of a path -- come out bit-identical to the
+// CPU's.  Checked on the host against libm's logf for all 1 056 964 609 normal floats in (0, 1]
+// (glibc 2.35, with and without fused multiply-adds): no mismatch.
+__device__ const double kLogfTab[16][2] = {
+    {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
+    {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},  {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
+    {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
+    {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1p+0, 0x0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
+    {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},
+    {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2},
+};
+__device__ __forceinline__ float rng_logf(float v) {
+    const uint32_t ix = __float_as_uint(v);
+    if (ix == 0x3f800000u) return 0.f;
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) & 15u);
+    const int k = (int)tmp >> 23;  // arithmetic shift
+    const uint32_t iz = ix - (tmp & (0x1ffu << 23));
+    const double invc = kLogfTab[i][0], logc = kLogfTab[i][1];
+    const double z = (double)__uint_as_float(iz);
+    const double r = z * invc - 1.0;
+    const double y0 = logc + (double)k * 0x1.62e42fefa39efp-1;
+    const double r2 = r * r;
+    double y = 0x1.5575b0be00b6ap-2 * r + -0x1.ffffef20a4123p-2;
+    y = -0x1.00ea348b88334p-2 * r2 + y;
+    y = y * r2 + (y0 + r);
+    return (float)y;
+}
 
 // normal_distribution<float>(0,1), Marsaglia polar; the distribution object is a temporary in
 // the reference, so its cached second variate is discarded and every call runs the loop and
@@ -339,16 +370,32 @@ __device__ __forceinline__ v3 primary_direction(const DevScene &S, uint32_t px, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// One path vertex of the reference estimator, in forward (throughput) form.
-// The reference recurses: L = k * L_next + emission (applyLight*, main.cpp:1128-1210); every hit
-// spawns exactly one continuation ray, so the recursion is the chain
-//   L = sum_i T_i * emission_i,  T_{i+1} = T_i * k_i
-// (same estimator and random numbers; only the rounding of the products differs).
+// One path vertex of the reference estimator (applyLight*, main.cpp:1128-1210).  Every hit spawns
+// exactly one continuation ray, so a sample is a chain of vertices.  sample_vertex() does what is
+// common to every way of evaluating that chain: the random decisions, the next ray, and a record
+// of HOW the vertex combines the radiance L_next coming back along that ray:
+//   kOpNone      miss or depth 0:                      L = 0
+//   kOpEmit      depth 1, or a diffuse vertex whose sampled direction is rejected:   L = e
+//   kOpDiffuse   L = color * L_next * (1/pi) * wn / pdf + e      (main.cpp:1139-1140)
+//   kOpMetal     L = color * L_next + e                          (main.cpp:1146)
+//   kOpPass      L = L_next + e      (dielectric reflection, refraction on the way out)
+//   kOpTint      L = L_next * color + e                          (refraction on the way in, 1181-1185)
+// The throughput kernels fold the chain forward (L += T e; T *= k: same estimator and random
+// numbers, different rounding of the same products); the replay kernel stores the records and
+// evaluates the recursion backwards in the reference's own operation order.
 // ---------------------------------------------------------------------------------------------
+enum VertexOp { kOpNone = 0, kOpEmit, kOpDiffuse, kOpMetal, kOpPass, kOpTint };
+
+struct Vertex {
+    int op;
+    uint32_t mat;
+    float wn, pdf;  // kOpDiffuse only
+};
+
 struct PathState {
     v3 o, d;      // current ray
-    v3 T;         // throughput
-    v3 L;         // radiance gathered so far by this sample
+    v3 T;         // throughput (forward evaluation)
+    v3 L;         // radiance gathered so far by this sample (forward evaluation)
     uint32_t rng; // engine state
     uint32_t depth;  // rayDepth the next hit is shaded with (main.cpp:1188-1199)
 };
@@ -376,19 +423,23 @@ __device__ __forceinline__ float light_pdf(const DevScene &S, v3 x, v3 w, int se
     return ps / (float)S.nlights;
 }
 
-// Shades the hit (t, tri) of ray (P.o, P.d).  Returns true when the path continues with the new
-// ray in P.o / P.d.
-__device__ __forceinline__ bool shade_hit(const DevScene &S, PathState &P, float t, int tri, uint32_t &lightTests) {
+// Processes the hit (t, tri) of ray (P.o, P.d): fills V, and when it returns true the path
+// continues with the new ray in P.o / P.d at depth P.depth - 1.  Touches P.o, P.d, P.rng, P.depth only.
+__device__ __forceinline__ bool sample_vertex(const DevScene &S, PathState &P, float t, int tri, Vertex &V,
+                                              uint32_t &lightTests) {
+    V.op = kOpNone;
+    V.mat = 0u;
+    V.wn = 0.f;
+    V.pdf = 1.f;
     if (tri < 0) return false;        // miss: backgroundColor is always (0,0,0), main.cpp:694, 1190
     if (P.depth == 0) return false;   // main.cpp:1195
     const float4 *tp = S.tris + 4 * (size_t)tri;
     const float4 q2 = tp[2], q3 = tp[3];
-    const DevMaterial M = S.mats[__float_as_uint(q3.y)];
-    const v3 color = mk(M.a.x, M.a.y, M.a.z);
-    const v3 emission = mk(M.b.x, M.b.y, M.b.z);
-    const int type = __float_as_int(M.a.w);
-    P.L = P.L + P.T * emission;       // every branch of applyLight* adds the emission
+    V.mat = __float_as_uint(q3.y);
+    V.op = kOpEmit;
     if (P.depth == 1) return false;   // main.cpp:1197
+    const DevMaterial M = S.mats[V.mat];
+    const int type = __float_as_int(M.a.w);
 
     // Intersection::update (main.cpp:84-95) for the winning triangle
     v3 n = normalize(mk(q2.y, q2.z, q2.w));
@@ -426,12 +477,14 @@ __device__ __forceinline__ bool shade_hit(const DevScene &S, PathState &P, float
         const float pc = (dn < kEps) ? 0.f : dn * kOneOverPi;
         const float pdf = 0.5f * pc + 0.5f * light_pdf(S, pPlus, w, tri, lightTests);
         const float wn = dot(w, n);
-        if (wn < 0.f || pdf < kEps) return false;
-        P.T = P.T * mk(color.x * kOneOverPi * wn / pdf, color.y * kOneOverPi * wn / pdf, color.z * kOneOverPi * wn / pdf);
+        if (wn < 0.f || pdf < kEps) return false;  // V.op stays kOpEmit, main.cpp:1134-1136
+        V.op = kOpDiffuse;
+        V.wn = wn;
+        V.pdf = pdf;
         P.o = pPlus;
         P.d = w;
     } else if (type == 1) {  // applyLightMetallic + getReflectedLight, main.cpp:1120-1126, 1143-1147
-        P.T = P.T * color;
+        V.op = kOpMetal;
         P.o = pPlus;
         P.d = normalize(P.d + 2.f * n * nl);
     } else {  // applyLightDielectric, main.cpp:1149-1186
@@ -452,17 +505,59 @@ __device__ __forceinline__ bool shade_hit(const DevScene &S, PathState &P, float
             reflect = rng_uniform(P.rng) < r;
         }
         if (reflect) {
+            V.op = kOpPass;
             P.o = pPlus;
             P.d = normalize(P.d + 2.f * n * nl);
         } else {
             const v3 rd = n12 * P.d + (n12 * nl - __builtin_sqrtf(1.f - sn * sn)) * n;
             P.d = normalize(rd);
             P.o = pMinus;
-            if (!inside) P.T = P.T * color;
+            V.op = inside ? kOpPass : kOpTint;
         }
     }
     --P.depth;
     return true;
+}
+
+// Forward evaluation of one vertex: L += T * e, T *= k.
+__device__ __forceinline__ void fold_forward(const DevScene &S, PathState &P, const Vertex &V) {
+    if (V.op == kOpNone) return;
+    const DevMaterial M = S.mats[V.mat];
+    const v3 color = mk(M.a.x, M.a.y, M.a.z);
+    P.L = P.L + P.T * mk(M.b.x, M.b.y, M.b.z);
+    if (V.op == kOpDiffuse)
+        P.T = P.T * mk(color.x * kOneOverPi * V.wn / V.pdf, color.y * kOneOverPi * V.wn / V.pdf,
+                       color.z * kOneOverPi * V.wn / V.pdf);
+    else if (V.op == kOpMetal || V.op == kOpTint)
+        P.T = P.T * color;
+}
+
+// Shades the hit (t, tri) of ray (P.o, P.d) in forward form.  Returns true when the path continues.
+__device__ __forceinline__ bool shade_hit(const DevScene &S, PathState &P, float t, int tri, uint32_t &lightTests) {
+    Vertex V;
+    const bool alive = sample_vertex(S, P, t, tri, V, lightTests);
+    fold_forward(S, P, V);
+    return alive;
+}
+
+// Backward evaluation of one vertex in the reference's operation order: returns this vertex's
+// radiance given the radiance `l` that came back along its continuation ray.
+__device__ __forceinline__ v3 fold_backward(const DevScene &S, int op, uint32_t mat, float wn, float pdf, v3 l) {
+    if (op == kOpNone) return mk(0.f, 0.f, 0.f);
+    const DevMaterial M = S.mats[mat];
+    const v3 color = mk(M.a.x, M.a.y, M.a.z);
+    const v3 e = mk(M.b.x, M.b.y, M.b.z);
+    if (op == kOpEmit) return e;
+    if (op == kOpDiffuse) {  // color * l * one_over_pi * wn / p + emission, left to right
+        v3 c = color * l;
+        c = c * kOneOverPi;
+        c = c * wn;
+        c = mk(c.x / pdf, c.y / pdf, c.z / pdf);
+        return c + e;
+    }
+    if (op == kOpMetal) return color * l + e;
+    if (op == kOpTint) return l * color + e;
+    return l + e;  // kOpPass
 }
 
 // ACES + gamma of generatePixel (main.cpp:1226-1231, 827-838) for one channel.

@@ -4,6 +4,7 @@
 //   k_intersect      closest hit for a caller-supplied ray batch      (intersectScene, main.cpp:1113)
 //   k_primary        camera ray of sample 0 per pixel + closest hit   (main.cpp:1212-1216, 1221)
 //   k_render_mega    persistent lane per pixel, path regeneration     (generatePixel's loop, main.cpp:1220-1225)
+//   k_render_replay  the reference's RNG stream and recursion order, bit-exact validation kernel
 //   wf_generate / wf_extend / wf_shade / wf_accumulate
 //                    the same estimator as queue-per-bounce kernels over SoA path records
 //   k_tonemap        mean, ACES, gamma, byte conversion               (main.cpp:1226-1231, 840-846)
@@ -135,6 +136,63 @@ __global__ __launch_bounds__(kBlock) void k_render_mega(DevScene S, rt::RenderPa
         ++segs;
         active = shade_hit(S, P, t, tri, lightTests);
         if (!active) acc = acc + P.L;  // color += generateSample(...), main.cpp:1224
+    }
+    sum[3 * (size_t)pix] = acc.x;
+    sum[3 * (size_t)pix + 1] = acc.y;
+    sum[3 * (size_t)pix + 2] = acc.z;
+    add_counters(S, segs, st, lightTests, COUNT);
+}
+
+// The reference's own evaluation order, for its own random stream: one lane per pixel, samples in
+// order with the engine carried across them (main.cpp:1221-1225), and each sample's chain of
+// vertices recorded and then folded BACKWARDS exactly as the recursion of applyLight* returns
+// (L = k * L_next + e, innermost first).  With the bit-exact closest hit and the restated
+// libstdc++ / glibc sampling code this reproduces the CPU path's radiance sums bit for bit; it is
+// the validation kernel, not the fast one.  rec: [depth][3][stride] words (op | material << 3,
+// wn, pdf), stride = threads of the launch.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_render_replay(DevScene S, rt::RenderParams rp, float *__restrict__ sum,
+                                                          uint32_t *__restrict__ rec, uint32_t stride) {
+    __shared__ int s_stack[kStack * kBlock];
+    uint32_t px, py;
+    if (!tile_pixel(rp.W, rp.H, px, py)) return;
+    const uint32_t pix = py * rp.W + px;
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    const v3 camPos = mk(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]);
+    PathState P;
+    P.rng = rng_seed(pix);
+    P.T = mk(1.f, 1.f, 1.f);
+    P.L = mk(0.f, 0.f, 0.f);
+    v3 acc = mk(0.f, 0.f, 0.f);
+    uint32_t segs = 0, lightTests = 0;
+    TraceStats st{0, 0, 0, 0};
+    for (uint32_t s = 0; s < rp.spp_count; ++s) {
+        if (rp.rng_mode == 1) P.rng = rng_seed(counter_seed(pix, rp.spp_begin + s, rp.seed));
+        P.d = primary_direction(S, px, py, rp.W, rp.H, P.rng);
+        P.o = camPos;
+        P.depth = rp.max_depth;
+        uint32_t nrec = 0;
+        for (;;) {
+            float t;
+            int tri;
+            closest_hit<COUNT>(S, P.o, P.d, s_stack + threadIdx.x, t, tri, st);
+            ++segs;
+            Vertex V;
+            const bool alive = sample_vertex(S, P, t, tri, V, lightTests);
+            uint32_t *r = rec + (size_t)nrec * 3u * stride + g;
+            r[0] = (uint32_t)V.op | (V.mat << 3);
+            r[stride] = __float_as_uint(V.wn);
+            r[2 * (size_t)stride] = __float_as_uint(V.pdf);
+            ++nrec;
+            if (!alive) break;
+        }
+        v3 l = mk(0.f, 0.f, 0.f);
+        for (uint32_t k = nrec; k-- > 0;) {
+            const uint32_t *r = rec + (size_t)k * 3u * stride + g;
+            const uint32_t w0 = r[0];
+            l = fold_backward(S, (int)(w0 & 7u), w0 >> 3, __uint_as_float(r[stride]), __uint_as_float(r[2 * (size_t)stride]), l);
+        }
+        acc = acc + l;  // color += generateSample(...), main.cpp:1224
     }
     sum[3 * (size_t)pix] = acc.x;
     sum[3 * (size_t)pix + 1] = acc.y;
@@ -394,6 +452,21 @@ hipError_t launch_render_mega(const DevScene &S, const RenderParams &rp, float *
     timer.begin(kKernMega, stream);
     if (count) hipLaunchKernelGGL(k_render_mega<true>, dim3(grid), dim3(kBlock), 0, stream, S, rp, radiance_sum);
     else hipLaunchKernelGGL(k_render_mega<false>, dim3(grid), dim3(kBlock), 0, stream, S, rp, radiance_sum);
+    timer.end(stream);
+    return hipGetLastError();
+}
+
+uint64_t replay_words(const RenderParams &rp) {
+    const uint64_t depth = rp.max_depth ? rp.max_depth : 1u;
+    return depth * 3u * (uint64_t)pixel_grid(rp.W, rp.H) * kBlock;
+}
+
+hipError_t launch_render_replay(const DevScene &S, const RenderParams &rp, float *radiance_sum, uint32_t *rec, bool count,
+                                hipStream_t stream, KernelTimer &timer) {
+    const uint32_t grid = pixel_grid(rp.W, rp.H);
+    timer.begin(kKernMega, stream);
+    if (count) hipLaunchKernelGGL(k_render_replay<true>, dim3(grid), dim3(kBlock), 0, stream, S, rp, radiance_sum, rec, grid * kBlock);
+    else hipLaunchKernelGGL(k_render_replay<false>, dim3(grid), dim3(kBlock), 0, stream, S, rp, radiance_sum, rec, grid * kBlock);
     timer.end(stream);
     return hipGetLastError();
 }

@@ -100,6 +100,10 @@ hipError_t launch_primary(const rtd::DevScene &S, uint32_t W, uint32_t H, uint32
                           hipStream_t stream, KernelTimer &timer);
 hipError_t launch_render_mega(const rtd::DevScene &S, const RenderParams &rp, float *radiance_sum, bool count,
                               hipStream_t stream, KernelTimer &timer);
+// Replay kernel (reference RNG stream, backward evaluation): words of per-lane vertex records it needs.
+uint64_t replay_words(const RenderParams &rp);
+hipError_t launch_render_replay(const rtd::DevScene &S, const RenderParams &rp, float *radiance_sum, uint32_t *rec,
+                                bool count, hipStream_t stream, KernelTimer &timer);
 hipError_t launch_render_wavefront(const rtd::DevScene &S, const RenderParams &rp, float *radiance_sum,
                                    const WavefrontBuffers &wb, bool count, hipStream_t stream, KernelTimer &timer);
 hipError_t launch_tonemap(const float *radiance_sum, uint64_t npixels, uint32_t spp, float *out_float,
