@@ -565,7 +565,10 @@ __device__ __forceinline__ float tonemap_channel(float sum, float spp) {
     const float x = sum / spp;
     float r = (x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f);
     r = __builtin_fminf(__builtin_fmaxf(r, 0.f), 1.f);
-    return __builtin_powf(r, 1.f / 2.2f);
+    // glm::pow -> powf.  Evaluated in double and rounded once: libm's powf is itself a double-precision
+    // kernel rounded to float, so the two agree except where a result sits within ~1e-10 relative of a
+    // rounding boundary (the device's single-precision powf differs in the last bit far more often).
+    return (float)::pow((double)r, (double)(1.f / 2.2f));
 }
 
 }  // namespace rtd

@@ -139,11 +139,13 @@ def test_tonemap_matches_oracle(scene_dir, oracle_mod):
     rs[:50] = 0
     f_o, b_o = oracle_mod.tonemap(rs, 16)
     f_g, b_g = gpu.tonemap(rs, 16)
-    # powf differs by an ulp or two between libm and the device library: floats to 1e-6 relative,
-    # bytes equal except where c*255 sits within that distance of an integer.
-    assert np.allclose(f_g, f_o, rtol=2e-6, atol=1e-7)
-    assert (b_g != b_o).mean() < 1e-3
-    assert np.abs(b_g.astype(int) - b_o.astype(int)).max() <= 1
+    # the device evaluates pow in double and rounds once; libm's powf is a double-precision kernel
+    # too, so floats agree except within rounding-boundary distance (<= 1 ulp on a handful), and the
+    # truncated bytes agree
+    assert np.allclose(f_g, f_o, rtol=1.2e-7, atol=0)
+    print("tonemap floats differing:", (f_g != f_o).sum(), "of", f_g.size)
+    assert (f_g != f_o).mean() < 1e-3
+    assert np.array_equal(b_g, b_o)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -301,3 +303,34 @@ def test_counting_launches_match_oracle_semantics(scene_dir, oracle_mod):
     assert c["nodes"] >= c["segments"] and c["tri_tests"] > 0
     # the oracle's own tree (2x inflated boxes, no pruning across subtrees) visits far more nodes
     assert c["nodes"] < c_o["nodes"]
+
+
+def test_command_line_end_to_end(scene_dir, oracle_mod, tmp_path):
+    """The reference's command line (main.cpp:1244-1259): `raytracing scene W H spp out.ppm` writes the
+    P6 file the CPU path would write -- same header, same bytes (the only inexact step is pow in the
+    gamma curve, at most 1 LSB on a pixel whose value sits on a rounding boundary)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT, make_scene
+    from oracle import gltf_ref
+    W, H, spp = 160, 120, 4
+    path = make_scene(scene_dir, "cornell")
+    sc = gltf_ref.parse_gltf(path, W, H)
+    orc = oracle_mod.OracleScene(sc["tri_verts"], sc["tri_material"], sc["materials"], sc["camera"])
+    ref, _ = orc.render(W, H, spp, max_depth=6, rng_mode=0)
+    _, want = oracle_mod.tonemap(ref, spp)
+    header = b"P6\n%d %d\n255\n" % (W, H)
+    for cmd in ([os.path.join(ROOT, "raytracing_amd", "bin", "raytracing")],
+                [sys.executable, "-m", "raytracing_amd"]):
+        out = str(tmp_path / "out.ppm")
+        r = subprocess.run(cmd + [path, str(W), str(H), str(spp), out], capture_output=True, text=True, cwd=ROOT,
+                           timeout=280)
+        assert r.returncode == 0, r.stderr
+        assert "Processed input after" in r.stdout and "Finished after" in r.stdout
+        data = open(out, "rb").read()
+        assert data.startswith(header) and len(data) == len(header) + W * H * 3
+        got = np.frombuffer(data[len(header):], dtype=np.uint8).reshape(-1, 3)
+        diff = np.abs(got.astype(int) - want.astype(int))
+        assert diff.max() <= 1 and (diff != 0).mean() < 1e-4
+        os.remove(out)
