@@ -134,8 +134,8 @@ def main():
 
     # ---- roofline of the dominant kernel -----------------------------------------------------------
     # Dominant kernel: wf_extend (closest hit of a ray queue) for the wavefront pipeline, k_render_mega
-    # for the megakernel.  Algorithmic bytes per ray segment: 64 B per BVH node visited (one node holds
-    # both child boxes), 48 B per ray/triangle test, plus per segment 36 B of queue traffic in the
+    # for the megakernel.  Algorithmic bytes per ray segment: 32 B per BVH node visited (one node holds
+    # both child boxes on a 16-bit grid), 48 B per ray/triangle test, plus per segment 36 B of queue traffic in the
     # wavefront kernel (24 B ray + 4 B queue index read, 8 B hit written); the megakernel instead reads
     # the 32 B shading record of the hit triangle and 64 B per light-pdf triangle test.  Visit counts
     # come from the counting build of the same kernels on the same workload (one extra launch outside
@@ -154,10 +154,10 @@ def main():
     seg_per_sample = c["segments"] / float(npix * count_spp)
     if pipeline == rt.PIPE_MEGAKERNEL:
         kname, kind = "k_render_mega", "mega"
-        bytes_per_seg = 64.0 * n_node + 48.0 * n_tri + 32.0 + 64.0 * n_light
+        bytes_per_seg = 32.0 * n_node + 48.0 * n_tri + 32.0 + 64.0 * n_light
     else:
         kname, kind = "wf_extend", "extend"
-        bytes_per_seg = 64.0 * n_node + 48.0 * n_tri + 36.0
+        bytes_per_seg = 32.0 * n_node + 48.0 * n_tri + 36.0
     k_ms, k_launches = ktimes[kind]
     launch_ms = k_ms / max(k_launches, 1)
     segs_per_launch = segs / float(max(k_launches, 1))

@@ -135,22 +135,28 @@ void rt_host_scene_free(rt_host_scene *hs);
 
 /* ---- scene upload: Triangle::update (main.cpp:527-536), the light list (1096-1098) and the
  * acceleration structure (BVH::build, main.cpp:552-558 / 608-686, here a binned-SAH builder
- * flattened to 64-byte nodes) ---- */
+ * flattened to 32-byte nodes) ---- */
 int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out);
 void rt_scene_destroy(rt_scene *s);
 int rt_scene_get_stats(const rt_scene *s, rt_scene_stats *out);
-/* Copies of the flattened structure for checkers: nodes (nnodes * 16 floats), triangles in
- * leaf order (ntri * 16 floats).  Either pointer may be NULL. */
-int rt_scene_get_flat(const rt_scene *s, float *nodes, float *tris);
+/* Copies of the flattened structure for checkers: the node grid (origin xyz, cell xyz), nodes
+ * (nnodes * 8 words, layout under rt_flat_get), triangles in leaf order (ntri * 16 floats).  Any
+ * pointer may be NULL. */
+int rt_scene_get_flat(const rt_scene *s, float grid[6], uint32_t *nodes, float *tris);
 
 /* Host-only view of the same build (no GPU call), for tools and checkers: builds the
  * acceleration structure of `desc` and hands out the flattened arrays exactly as rt_scene_create
  * would upload them.  info[0] = node count, [1] = triangle count, [2] = light count,
- * [3] = tree height (inner levels).  nodes: nnodes*16 floats, tris: ntri*16 floats (leaf order),
- * lights: leaf-order positions of the emissive triangles in loader order; any may be NULL. */
+ * [3] = tree height (inner levels).  grid: origin xyz then cell xyz of the 16-bit node grid.
+ * nodes: nnodes*8 words; words 0-2 = left child's box (one word per axis: lo | hi << 16, plane =
+ * origin + q * cell, rounded outward), 3-5 = right child's box, 6-7 = child references (>= 0 node
+ * index, < 0 leaf: ~ref = first << 3 | count-1).  tris: ntri*16 floats, leaf order (A, AB, AC,
+ * cross(AB,AC), loader id, material, 2/|N|, 0).  lights: leaf-order positions of the emissive
+ * triangles in loader order.  Any pointer may be NULL. */
 typedef struct rt_flat rt_flat;
 int rt_flat_build(const rt_scene_desc *desc, rt_flat **out);
-int rt_flat_get(const rt_flat *f, uint32_t info[4], float *nodes, float *tris, uint32_t *lights);
+int rt_flat_get(const rt_flat *f, uint32_t info[4], float grid[6], uint32_t *nodes, float *tris,
+                uint32_t *lights);
 void rt_flat_free(rt_flat *f);
 
 /* ---- closest hit: stands in for intersectScene / BVH::intersect, main.cpp:1113, 560-605 ---- */

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librt_amd.so")
+# RT_AMD_LIB names another build of the same library (kernel experiments, counting builds)
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "lib", "librt_amd.so")
 
 RT_OK = 0
 RNG_REFERENCE, RNG_COUNTER = 0, 1
@@ -58,9 +59,9 @@ SIGNATURES = {
     "rt_scene_create": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]),
     "rt_scene_destroy": (None, [C.c_void_p]),
     "rt_scene_get_stats": (C.c_int, [C.c_void_p, C.POINTER(SceneStats)]),
-    "rt_scene_get_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_scene_get_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_flat_build": (C.c_int, [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]),
-    "rt_flat_get": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_flat_get": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_flat_free": (None, [C.c_void_p]),
     "rt_intersect_rays": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_intersect_rays_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

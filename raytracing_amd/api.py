@@ -81,9 +81,19 @@ def load_gltf(path, width, height):
     return HostScene(tv, tm, mats, cam)
 
 
+def node_boxes(nodes, grid):
+    """Decodes the 16-bit node boxes: (n, 2, 6) float64, per child lo xyz then hi xyz
+    (plane = origin + q * cell; see rt_flat_get in include/rt_amd.h)."""
+    q = nodes[:, :6].reshape(-1, 2, 3)
+    origin, cell = grid[:3].astype(np.float64), grid[3:].astype(np.float64)
+    lo = origin + (q & 0xFFFF).astype(np.float64) * cell
+    hi = origin + (q >> 16).astype(np.float64) * cell
+    return np.concatenate([lo, hi], axis=2)
+
+
 def build_flat(host_scene):
-    """Host-only acceleration-structure build (no GPU): returns dict(nodes (n,16) f32, tris (m,16) f32,
-    lights (k,) u32 leaf-order positions, height)."""
+    """Host-only acceleration-structure build (no GPU): returns dict(nodes (n,8) u32, grid (6,) f32,
+    tris (m,16) f32, lights (k,) u32 leaf-order positions, height)."""
     if isinstance(host_scene, dict):
         host_scene = HostScene(**host_scene)
     L = _lib.lib()
@@ -92,14 +102,15 @@ def build_flat(host_scene):
     check(L.rt_flat_build(C.byref(d), C.byref(h)))
     try:
         info = np.zeros(4, dtype=np.uint32)
-        check(L.rt_flat_get(h, _p(info), None, None, None))
-        nodes = np.empty((int(info[0]), 16), dtype=np.float32)
+        check(L.rt_flat_get(h, _p(info), None, None, None, None))
+        grid = np.empty(6, dtype=np.float32)
+        nodes = np.empty((int(info[0]), 8), dtype=np.uint32)
         tris = np.empty((int(info[1]), 16), dtype=np.float32)
         lights = np.empty(int(info[2]), dtype=np.uint32)
-        check(L.rt_flat_get(h, None, _p(nodes), _p(tris), _p(lights) if lights.size else None))
+        check(L.rt_flat_get(h, None, _p(grid), _p(nodes), _p(tris), _p(lights) if lights.size else None))
     finally:
         L.rt_flat_free(h)
-    return dict(nodes=nodes, tris=tris, lights=lights, height=int(info[3]))
+    return dict(nodes=nodes, grid=grid, tris=tris, lights=lights, height=int(info[3]))
 
 
 class Scene:
@@ -140,10 +151,11 @@ class Scene:
 
     def flat(self):
         st = self.stats()
-        nodes = np.empty((st["nnodes"], 16), dtype=np.float32)
+        grid = np.empty(6, dtype=np.float32)
+        nodes = np.empty((st["nnodes"], 8), dtype=np.uint32)
         tris = np.empty((st["ntri"], 16), dtype=np.float32)
-        check(_lib.lib().rt_scene_get_flat(self._h, _p(nodes), _p(tris)))
-        return nodes, tris
+        check(_lib.lib().rt_scene_get_flat(self._h, _p(grid), _p(nodes), _p(tris)))
+        return grid, nodes, tris
 
     def set_counting(self, enable):
         check(_lib.lib().rt_set_counting(self._h, int(bool(enable))))

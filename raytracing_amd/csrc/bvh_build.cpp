@@ -293,27 +293,57 @@ void build_flat_scene(const rt_scene_desc &desc, FlatScene &out) {
     out.nnodes = nnodes;
     out.ntri = n;
     out.tree_height = height;
-    out.nodes.assign((size_t)nnodes * 16, 0.f);
+
+    // Node boxes go to the device on a 16-bit grid spanning the (padded) scene bounds:
+    //   plane = grid_origin + q * grid_cell,  q in [0, 65535],
+    // rounded outward, plus two guard cells per side.  The kernels evaluate a plane distance as one FMA
+    // with per-ray constants cell/d and (origin - o)/d; its rounding error is a few ulps of the scene
+    // extent (about 1e-7 of it), the guard is two cells (3e-5 of it).
+    auto real = [](const Box &b) { return b.lo[0] <= b.hi[0] && b.lo[0] < 1.0e30f; };
+    float glo[3] = {3.0e30f, 3.0e30f, 3.0e30f}, ghi[3] = {-3.0e30f, -3.0e30f, -3.0e30f};
+    for (uint32_t k = 0; k < nnodes; ++k)
+        for (int c = 0; c < 2; ++c) {
+            const Box &b = B.nodes[k].box[c];
+            if (!real(b)) continue;
+            for (int a = 0; a < 3; ++a) {
+                glo[a] = std::min(glo[a], pad_lo(b.lo[a]));
+                ghi[a] = std::max(ghi[a], pad_hi(b.hi[a]));
+            }
+        }
+    for (int a = 0; a < 3; ++a) {
+        if (glo[a] > ghi[a]) glo[a] = 0.f, ghi[a] = 1.f;  // no triangles at all
+        const float mag = std::max(1.f, std::max(std::fabs(glo[a]), std::fabs(ghi[a])));
+        const float ext = std::max(ghi[a] - glo[a], 1.0e-3f * mag);  // flat scenes still get a usable cell
+        out.grid_cell[a] = ext / 65000.f;
+        out.grid_origin[a] = glo[a] - 16.f * out.grid_cell[a];
+    }
+    auto quantise = [&](float v, int a, bool up) -> uint32_t {
+        const double o = out.grid_origin[a], c = out.grid_cell[a];
+        long q = (long)(up ? std::ceil(((double)v - o) / c) : std::floor(((double)v - o) / c));
+        if (up) {
+            while (o + (double)q * c < (double)v) ++q;
+            q += 2;
+        } else {
+            while (o + (double)q * c > (double)v) --q;
+            q -= 2;
+        }
+        if (q < 0 || q > 65535) throw std::runtime_error("internal: box outside the node grid");
+        return (uint32_t)q;
+    };
+    out.nodes.assign((size_t)nnodes * 8, 0u);
     for (uint32_t k = 0; k < nnodes; ++k) {
         const BNode &nd = B.nodes[order[k]];
-        float *q = &out.nodes[(size_t)k * 16];
-        const Box &L = nd.box[0], &R = nd.box[1];
-        const bool lreal = L.lo[0] <= L.hi[0] && L.lo[0] < 1.0e30f;
-        const bool rreal = R.lo[0] <= R.hi[0] && R.lo[0] < 1.0e30f;
-        float l[6], r[6];
-        for (int a = 0; a < 3; ++a) {
-            l[a] = lreal ? pad_lo(L.lo[a]) : L.lo[a];
-            l[3 + a] = lreal ? pad_hi(L.hi[a]) : L.hi[a];
-            r[a] = rreal ? pad_lo(R.lo[a]) : R.lo[a];
-            r[3 + a] = rreal ? pad_hi(R.hi[a]) : R.hi[a];
+        uint32_t *w = &out.nodes[(size_t)k * 8];
+        for (int c = 0; c < 2; ++c) {
+            const Box &b = nd.box[c];
+            for (int a = 0; a < 3; ++a) {
+                // an absent child: a point in the far corner of the grid, outside every real box
+                const uint32_t lo = real(b) ? quantise(pad_lo(b.lo[a]), a, false) : 65535u;
+                const uint32_t hi = real(b) ? quantise(pad_hi(b.hi[a]), a, true) : 65535u;
+                w[3 * c + a] = lo | (hi << 16);
+            }
+            w[6 + c] = (uint32_t)(nd.child[c] >= 0 ? (int32_t)newIndex[nd.child[c]] : nd.child[c]);
         }
-        q[0] = l[0]; q[1] = l[1]; q[2] = l[2]; q[3] = l[3];
-        q[4] = l[4]; q[5] = l[5]; q[6] = r[0]; q[7] = r[1];
-        q[8] = r[2]; q[9] = r[3]; q[10] = r[4]; q[11] = r[5];
-        int32_t c0 = nd.child[0] >= 0 ? (int32_t)newIndex[nd.child[0]] : nd.child[0];
-        int32_t c1 = nd.child[1] >= 0 ? (int32_t)newIndex[nd.child[1]] : nd.child[1];
-        q[12] = bits_to_float((uint32_t)c0);
-        q[13] = bits_to_float((uint32_t)c1);
     }
 
     // Triangles in leaf order, with the derived data of Triangle::update (main.cpp:527-536).
@@ -380,7 +410,7 @@ int rt_flat_build(const rt_scene_desc *desc, rt_flat **out) {
     return RT_OK;
 }
 
-int rt_flat_get(const rt_flat *f, uint32_t info[4], float *nodes, float *tris, uint32_t *lights) {
+int rt_flat_get(const rt_flat *f, uint32_t info[4], float grid[6], uint32_t *nodes, float *tris, uint32_t *lights) {
     if (!f) {
         rt::set_error("rt_flat_get: null argument");
         return RT_ERR_INVALID;
@@ -392,7 +422,12 @@ int rt_flat_get(const rt_flat *f, uint32_t info[4], float *nodes, float *tris, u
         info[2] = (uint32_t)s.lights.size();
         info[3] = s.tree_height;
     }
-    if (nodes) std::memcpy(nodes, s.nodes.data(), (size_t)s.nnodes * 16 * sizeof(float));
+    if (grid)
+        for (int a = 0; a < 3; ++a) {
+            grid[a] = s.grid_origin[a];
+            grid[3 + a] = s.grid_cell[a];
+        }
+    if (nodes) std::memcpy(nodes, s.nodes.data(), (size_t)s.nnodes * 8 * sizeof(uint32_t));
     if (tris) std::memcpy(tris, s.tris.data(), (size_t)s.ntri * 16 * sizeof(float));
     if (lights && !s.lights.empty()) std::memcpy(lights, s.lights.data(), s.lights.size() * sizeof(uint32_t));
     return RT_OK;

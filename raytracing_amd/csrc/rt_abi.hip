@@ -22,7 +22,7 @@ struct rt_scene {
     int device = 0;
     rt::FlatScene flat;
     rtd::DevScene view{};
-    float4 *d_nodes = nullptr;
+    uint4 *d_nodes = nullptr;
     float4 *d_tris = nullptr;
     uint32_t *d_lights = nullptr;
     rtd::DevMaterial *d_mats = nullptr;
@@ -196,7 +196,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     RT_TRY(dev_alloc(s, &s->d_lights, f.lights.size()));
     RT_TRY(dev_alloc(s, &s->d_mats, mats.size()));
     RT_TRY(dev_alloc(s, &s->d_counters, kCounterWords));
-    RT_TRY(hipMemcpy(s->d_nodes, f.nodes.data(), f.nodes.size() * sizeof(float), hipMemcpyHostToDevice));
+    RT_TRY(hipMemcpy(s->d_nodes, f.nodes.data(), f.nodes.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     RT_TRY(hipMemcpy(s->d_tris, f.tris.data(), f.tris.size() * sizeof(float), hipMemcpyHostToDevice));
     if (!f.lights.empty())
         RT_TRY(hipMemcpy(s->d_lights, f.lights.data(), f.lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -211,6 +211,8 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     v.counters = s->d_counters;
     v.nlights = (uint32_t)f.lights.size();
     for (int k = 0; k < 3; ++k) {
+        v.grid_origin[k] = f.grid_origin[k];
+        v.grid_cell[k] = f.grid_cell[k];
         v.cam_pos[k] = desc->camera.position[k];
         v.cam_right[k] = desc->camera.right[k];
         v.cam_up[k] = desc->camera.up[k];
@@ -247,9 +249,14 @@ int rt_scene_get_stats(const rt_scene *s, rt_scene_stats *out) {
     return RT_OK;
 }
 
-int rt_scene_get_flat(const rt_scene *s, float *nodes, float *tris) {
+int rt_scene_get_flat(const rt_scene *s, float grid[6], uint32_t *nodes, float *tris) {
     if (!s) return fail(RT_ERR_INVALID, "rt_scene_get_flat: null scene");
-    if (nodes) std::memcpy(nodes, s->flat.nodes.data(), (size_t)s->flat.nnodes * 16 * sizeof(float));
+    if (grid)
+        for (int a = 0; a < 3; ++a) {
+            grid[a] = s->flat.grid_origin[a];
+            grid[3 + a] = s->flat.grid_cell[a];
+        }
+    if (nodes) std::memcpy(nodes, s->flat.nodes.data(), (size_t)s->flat.nnodes * 8 * sizeof(uint32_t));
     if (tris) std::memcpy(tris, s->flat.tris.data(), (size_t)s->flat.ntri * 16 * sizeof(float));
     return RT_OK;
 }

@@ -144,12 +144,13 @@ struct DevMaterial {
 };
 
 struct DevScene {
-    const float4 *nodes;      // 4 x float4 per node
+    const uint4 *nodes;       // 2 x uint4 per node: 16-bit grid boxes of both children + two references
     const float4 *tris;       // 4 x float4 per triangle, leaf order
     const uint32_t *lights;   // leaf-order positions of the emissive triangles
     const DevMaterial *mats;
     unsigned long long *counters;  // kCounterShards x kCounterStride; per shard [0] segments [1] nodes [2] tri tests [3] light tests
     uint32_t nlights;
+    float grid_origin[3], grid_cell[3];  // node-box plane = origin + q * cell, q a 16-bit integer
     float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];
     float tan_x, tan_y;
 };
@@ -201,26 +202,6 @@ __device__ __forceinline__ bool tri_test(float4 q0, float4 q1, float4 q2, v3 o, 
     return !(u < 0.f || v < 0.f || t < 0.f || u + v > 1.f);
 }
 
-// Conservative slab test against a padded box: plane distances as one FMA each,
-// t = plane * (1/d) - o * (1/d).  That rounds differently from (plane - o) / d, by at most a few
-// ulps of |o / d| in t, i.e. a few ulps of |o| in position -- far inside the padding the host put
-// on every box (1e-5 + 4e-7 |coordinate|).  The reciprocal direction is clamped to +-1e30 (see
-// Traversal::start) so that no inf - inf = NaN can arise for axis-parallel rays: a NaN on one plane
-// of a slab would silently turn min/max of the pair into the other plane's value, a false miss.
-// A NaN DIRECTION still makes every comparison fail: a miss, like the reference (main.cpp:1158).
-__device__ __forceinline__ bool box_test(float lox, float loy, float loz, float hix, float hiy, float hiz, v3 id,
-                                         v3 nob, float tBest, float &tNear) {
-    const float ax = __builtin_fmaf(lox, id.x, nob.x), bx = __builtin_fmaf(hix, id.x, nob.x);
-    const float ay = __builtin_fmaf(loy, id.y, nob.y), by = __builtin_fmaf(hiy, id.y, nob.y);
-    const float az = __builtin_fmaf(loz, id.z, nob.z), bz = __builtin_fmaf(hiz, id.z, nob.z);
-    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
-                                     __builtin_fminf(az, bz));
-    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
-                                     __builtin_fmaxf(az, bz));
-    tNear = tn;
-    return (tn <= tf * 1.0000004f) & (tf >= 0.f) & (tn < tBest);
-}
-
 // Closest hit (BVH::intersect, main.cpp:560-605): the minimum-t triangle among all triangles the
 // ray hits.  A hit needs t < INF (1e4): the reference prunes every subtree at that distance until a
 // first hit is found.
@@ -240,7 +221,11 @@ constexpr int kSentinel = 0x7FFFFFFF;  // "stack is empty": never a node index, 
 
 template <bool COUNT, int EXIT_LANES = 0>
 struct Traversal {
-    v3 o, d, id, nob;  // origin, direction, 1/d, -o/d
+    struct f2 {
+        float x, y;
+    };
+    v3 o, d, ga, gb;  // origin, direction, cell/d, (grid origin - o)/d: plane distance t = q * ga + gb
+    uint32_t rx, ry, rz;  // 16 where the direction component is negative (the near plane is the high one), else 0
     float tBest;
     int triBest;
     int cur;   // >= 0 inner node to visit, < 0 leaf reference, kSentinel = nothing left
@@ -257,14 +242,20 @@ struct Traversal {
         if (__builtin_fabsf(v) < 1.0e-30f) v = __builtin_copysignf(1.0e-30f, v);
         return 1.f / v;
     }
-    __device__ __forceinline__ void start(v3 ro, v3 rd) {
+    __device__ __forceinline__ void start(const DevScene &S, v3 ro, v3 rd) {
         o = ro;
         d = rd;
-        id = mk(recip_clamped(rd.x), recip_clamped(rd.y), recip_clamped(rd.z));
-        nob = mk(-(ro.x * id.x), -(ro.y * id.y), -(ro.z * id.z));
+        const v3 r = mk(recip_clamped(rd.x), recip_clamped(rd.y), recip_clamped(rd.z));
+        ga = mk(S.grid_cell[0] * r.x, S.grid_cell[1] * r.y, S.grid_cell[2] * r.z);
+        gb = mk((S.grid_origin[0] - ro.x) * r.x, (S.grid_origin[1] - ro.y) * r.y, (S.grid_origin[2] - ro.z) * r.z);
+        rx = (__float_as_uint(ga.x) >> 31) << 4;
+        ry = (__float_as_uint(ga.y) >> 31) << 4;
+        rz = (__float_as_uint(ga.z) >> 31) << 4;
         tBest = kInf;
         triBest = -1;
-        cur = 0;
+        // a NaN direction hits nothing (every comparison of main.cpp:1158 fails); here it must not walk
+        // the tree either, because max(NaN, 0) <= min(NaN, tBest) would hold for every box
+        cur = (rd.x + rd.y + rd.z) == (rd.x + rd.y + rd.z) ? 0 : kSentinel;
         leaf = 0;
         sp = 0;
     }
@@ -283,19 +274,34 @@ struct Traversal {
         stack[sp * kBlock] = ref;
         ++sp;
     }
+    // One axis of one child box, word = lo | hi << 16: rotating the word by 16 bits for a negative
+    // direction puts the near plane in the low half, so no min/max per axis is needed.  Returns the
+    // (near, far) plane distances.  Two scalar FMAs: v_pk_fma_f32 measured 4 % slower here.
+    static __device__ __forceinline__ f2 slab(uint32_t w, uint32_t rot, float a, float b) {
+        const uint32_t u = __builtin_amdgcn_alignbit(w, w, rot);
+        return f2{__builtin_fmaf((float)(u & 0xffffu), a, b), __builtin_fmaf((float)(u >> 16), a, b)};
+    }
 
     // One round: walk inner nodes until this lane holds a leaf (or has nothing left), then test
     // the triangles of the leaves it holds.
     __device__ __forceinline__ void step(const DevScene &S, TraceStats &st) {
         const uint32_t nodes0 = st.nodes, tris0 = st.tris;
         while (cur >= 0 && cur != kSentinel) {
-            const float4 *np = S.nodes + 4 * (size_t)cur;
-            const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            const uint4 *np = S.nodes + 2 * (size_t)cur;
+            const uint4 n0 = np[0], n1 = np[1];
             if (COUNT) ++st.nodes;
-            float tnL, tnR;
-            const bool hL = box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, id, nob, tBest, tnL);
-            const bool hR = box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, id, nob, tBest, tnR);
-            const int cl = __float_as_int(n3.x), cr = __float_as_int(n3.y);
+            // Conservative slab test on the node's 16-bit grid boxes.  The host rounded every box
+            // outward and added two guard cells per side, far more than the rounding of these FMAs
+            // (a few ulps of the scene's extent), so no box is thinner than four cells and plain
+            // near <= far needs no tolerance.  x = near plane, y = far plane after the rotation.
+            const f2 lx = slab(n0.x, rx, ga.x, gb.x), ly = slab(n0.y, ry, ga.y, gb.y), lz = slab(n0.z, rz, ga.z, gb.z);
+            const f2 qx = slab(n0.w, rx, ga.x, gb.x), qy = slab(n1.x, ry, ga.y, gb.y), qz = slab(n1.y, rz, ga.z, gb.z);
+            const float tnL = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(lx.x, ly.x), lz.x), 0.f);
+            const float tfL = __builtin_fminf(__builtin_fminf(__builtin_fminf(lx.y, ly.y), lz.y), tBest);
+            const float tnR = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(qx.x, qy.x), qz.x), 0.f);
+            const float tfR = __builtin_fminf(__builtin_fminf(__builtin_fminf(qx.y, qy.y), qz.y), tBest);
+            const bool hL = tnL <= tfL, hR = tnR <= tfR;
+            const int cl = (int)n1.z, cr = (int)n1.w;
             if (hL && hR) {
                 const bool leftFirst = tnL <= tnR;
                 push(leftFirst ? cr : cl);
@@ -348,7 +354,7 @@ __device__ __forceinline__ void closest_hit(const DevScene &S, v3 o, v3 d, int *
                                             TraceStats &st) {
     Traversal<COUNT> T;
     T.bind(stack);
-    T.start(o, d);
+    T.start(S, o, d);
     while (!T.done()) T.step(S, st);
     tBest = T.tBest;
     triBest = T.triBest;

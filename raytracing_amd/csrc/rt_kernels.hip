@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
                     const v3 o = mk(V.ray[slot], V.ray[V.cap + slot], V.ray[2 * (size_t)V.cap + slot]);
                     const v3 d = mk(V.ray[3 * (size_t)V.cap + slot], V.ray[4 * (size_t)V.cap + slot],
                                     V.ray[5 * (size_t)V.cap + slot]);
-                    T.start(o, d);
+                    T.start(S, o, d);
                     hasRay = true;
                 }
                 chunkNext += take;
