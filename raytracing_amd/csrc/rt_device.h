@@ -406,24 +406,55 @@ struct PathState {
     uint32_t depth;  // rayDepth the next hit is shaded with (main.cpp:1188-1199)
 };
 
+// The first kLdsLights light triangles, copied into LDS by every workgroup of a shading kernel:
+// every diffuse vertex tests its new direction against ALL lights (light_pdf below), the same few
+// records for every lane, and fetching them through the vector-memory path was more than half of
+// the shading kernel's load instructions.
+constexpr uint32_t kLdsLights = 64;
+struct LightCache {
+    const float4 *recs;  // LDS: 4 x float4 per cached light, light-list order
+    const int *ids;      // LDS: leaf-order triangle position of each cached light
+    uint32_t n;          // lights cached: min(S.nlights, kLdsLights)
+};
+
+// Call from all threads of the workgroup; ends with a barrier.
+__device__ __forceinline__ LightCache load_light_cache(const DevScene &S, float4 *recs, int *ids) {
+    const uint32_t n = S.nlights < kLdsLights ? S.nlights : kLdsLights;
+    for (uint32_t e = threadIdx.x; e < 4u * n; e += kBlock) recs[e] = S.tris[4 * (size_t)S.lights[e >> 2] + (e & 3u)];
+    for (uint32_t k = threadIdx.x; k < n; k += kBlock) ids[k] = (int)S.lights[k];
+    __syncthreads();
+    return LightCache{recs, ids, n};
+}
+
+// Triangle::pdf (main.cpp:510-517) of a light triangle the ray x + t w hits
+__device__ __forceinline__ float light_term(float4 q2, float4 q3, v3 x, v3 w, float t) {
+    v3 n = normalize(mk(q2.y, q2.z, q2.w));
+    if (dot(n, w) > 0.f) n = n * -1.f;
+    const v3 ip = x + t * w;
+    const v3 r = ip - x;
+    return q3.z * dot(r, r) / __builtin_fabsf(dot(normalize(r), n));
+}
+
 // LightSurface::pdf (main.cpp:771-783): sum over all lights except the surface's own triangle
-// of Triangle::pdf (main.cpp:510-517), no occlusion test, divided by the light count.
-__device__ __forceinline__ float light_pdf(const DevScene &S, v3 x, v3 w, int self, uint32_t &tests) {
+// of Triangle::pdf, in light-list order, no occlusion test, divided by the light count.  A light
+// the ray misses adds nothing (the reference skips it; here its term is never added either).
+__device__ __forceinline__ float light_pdf(const DevScene &S, const LightCache &LC, v3 x, v3 w, int self,
+                                           uint32_t &tests) {
     float ps = 0.f;
-    for (uint32_t k = 0; k < S.nlights; ++k) {
+    for (uint32_t k = 0; k < LC.n; ++k) {
+        if (LC.ids[k] == self) continue;
+        ++tests;
+        const float4 *tp = LC.recs + 4 * k;
+        float t;
+        if (tri_test(tp[0], tp[1], tp[2], x, w, t)) ps += light_term(tp[2], tp[3], x, w, t);
+    }
+    for (uint32_t k = LC.n; k < S.nlights; ++k) {
         const int lt = (int)S.lights[k];
         if (lt == self) continue;
         ++tests;
         const float4 *tp = S.tris + 4 * (size_t)lt;
-        const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
         float t;
-        if (tri_test(q0, q1, q2, x, w, t)) {
-            v3 n = normalize(mk(q2.y, q2.z, q2.w));
-            if (dot(n, w) > 0.f) n = n * -1.f;
-            const v3 ip = x + t * w;
-            const v3 r = ip - x;
-            ps += q3.z * dot(r, r) / __builtin_fabsf(dot(normalize(r), n));
-        }
+        if (tri_test(tp[0], tp[1], tp[2], x, w, t)) ps += light_term(tp[2], tp[3], x, w, t);
     }
     if (ps < kEps || __builtin_isnan(ps) || __builtin_isinf(ps)) return 0.f;
     return ps / (float)S.nlights;
@@ -431,8 +462,8 @@ __device__ __forceinline__ float light_pdf(const DevScene &S, v3 x, v3 w, int se
 
 // Processes the hit (t, tri) of ray (P.o, P.d): fills V, and when it returns true the path
 // continues with the new ray in P.o / P.d at depth P.depth - 1.  Touches P.o, P.d, P.rng, P.depth only.
-__device__ __forceinline__ bool sample_vertex(const DevScene &S, PathState &P, float t, int tri, Vertex &V,
-                                              uint32_t &lightTests) {
+__device__ __forceinline__ bool sample_vertex(const DevScene &S, const LightCache &LC, PathState &P, float t, int tri,
+                                              Vertex &V, uint32_t &lightTests) {
     V.op = kOpNone;
     V.mat = 0u;
     V.wn = 0.f;
@@ -481,7 +512,7 @@ __device__ __forceinline__ bool sample_vertex(const DevScene &S, PathState &P, f
         }
         const float dn = dot(w, n);  // Cosine::pdf, main.cpp:748-754
         const float pc = (dn < kEps) ? 0.f : dn * kOneOverPi;
-        const float pdf = 0.5f * pc + 0.5f * light_pdf(S, pPlus, w, tri, lightTests);
+        const float pdf = 0.5f * pc + 0.5f * light_pdf(S, LC, pPlus, w, tri, lightTests);
         const float wn = dot(w, n);
         if (wn < 0.f || pdf < kEps) return false;  // V.op stays kOpEmit, main.cpp:1134-1136
         V.op = kOpDiffuse;
@@ -539,9 +570,10 @@ __device__ __forceinline__ void fold_forward(const DevScene &S, PathState &P, co
 }
 
 // Shades the hit (t, tri) of ray (P.o, P.d) in forward form.  Returns true when the path continues.
-__device__ __forceinline__ bool shade_hit(const DevScene &S, PathState &P, float t, int tri, uint32_t &lightTests) {
+__device__ __forceinline__ bool shade_hit(const DevScene &S, const LightCache &LC, PathState &P, float t, int tri,
+                                          uint32_t &lightTests) {
     Vertex V;
-    const bool alive = sample_vertex(S, P, t, tri, V, lightTests);
+    const bool alive = sample_vertex(S, LC, P, t, tri, V, lightTests);
     fold_forward(S, P, V);
     return alive;
 }

@@ -102,6 +102,9 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, uint32_t W, uint
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_render_mega(DevScene S, rt::RenderParams rp, float *__restrict__ sum) {
     __shared__ int s_stack[kStack * kBlock];
+    __shared__ float4 s_lrec[4 * rtd::kLdsLights];
+    __shared__ int s_lid[rtd::kLdsLights];
+    const LightCache LC = load_light_cache(S, s_lrec, s_lid);
     uint32_t px, py;
     if (!tile_pixel(rp.W, rp.H, px, py)) return;
     const uint32_t pix = py * rp.W + px;
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(kBlock) void k_render_mega(DevScene S, rt::RenderPa
         int tri;
         closest_hit<COUNT>(S, P.o, P.d, s_stack + threadIdx.x, t, tri, st);
         ++segs;
-        active = shade_hit(S, P, t, tri, lightTests);
+        active = shade_hit(S, LC, P, t, tri, lightTests);
         if (!active) acc = acc + P.L;  // color += generateSample(...), main.cpp:1224
     }
     sum[3 * (size_t)pix] = acc.x;
@@ -154,6 +157,9 @@ template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_render_replay(DevScene S, rt::RenderParams rp, float *__restrict__ sum,
                                                           uint32_t *__restrict__ rec, uint32_t stride) {
     __shared__ int s_stack[kStack * kBlock];
+    __shared__ float4 s_lrec[4 * rtd::kLdsLights];
+    __shared__ int s_lid[rtd::kLdsLights];
+    const LightCache LC = load_light_cache(S, s_lrec, s_lid);
     uint32_t px, py;
     if (!tile_pixel(rp.W, rp.H, px, py)) return;
     const uint32_t pix = py * rp.W + px;
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void k_render_replay(DevScene S, rt::Render
             closest_hit<COUNT>(S, P.o, P.d, s_stack + threadIdx.x, t, tri, st);
             ++segs;
             Vertex V;
-            const bool alive = sample_vertex(S, P, t, tri, V, lightTests);
+            const bool alive = sample_vertex(S, LC, P, t, tri, V, lightTests);
             uint32_t *r = rec + (size_t)nrec * 3u * stride + g;
             r[0] = (uint32_t)V.op | (V.mat << 3);
             r[stride] = __float_as_uint(V.wn);
@@ -329,6 +335,9 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const u
                                                     uint32_t *__restrict__ cursor) {
     __shared__ uint32_t s_buf[kAppendBuf];
     __shared__ uint32_t s_count, s_base;
+    __shared__ float4 s_lrec[4 * rtd::kLdsLights];
+    __shared__ int s_lid[rtd::kLdsLights];
+    const LightCache LC = load_light_cache(S, s_lrec, s_lid);
     const uint32_t count = *qcount_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) *cursor = 0u;  // work cursor of the next extend pass
     if (threadIdx.x == 0) s_count = 0u;
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const u
             P.L = mk(V.rad[i], V.rad[V.cap + i], V.rad[2 * (size_t)V.cap + i]);
             P.rng = V.rng[i];
             P.depth = V.meta[i];
-            alive = shade_hit(S, P, V.hit_t[i], V.hit_tri[i], lightTests);
+            alive = shade_hit(S, LC, P, V.hit_t[i], V.hit_tri[i], lightTests);
             V.rad[i] = P.L.x;
             V.rad[V.cap + i] = P.L.y;
             V.rad[2 * (size_t)V.cap + i] = P.L.z;
