@@ -78,12 +78,7 @@ hipError_t dev_alloc(rt_scene *s, T **p, size_t count) {
 void free_wavefront(rt_scene *s) {
     rt::WavefrontBuffers &w = s->wf;
     (void)hipFree(w.ray);
-    (void)hipFree(w.thr);
-    (void)hipFree(w.rad);
-    (void)hipFree(w.rng);
-    (void)hipFree(w.meta);
-    (void)hipFree(w.hit_t);
-    (void)hipFree(w.hit_tri);
+    (void)hipFree(w.state);
     (void)hipFree(w.queue[0]);
     (void)hipFree(w.queue[1]);
     (void)hipFree(w.qcount);
@@ -106,13 +101,8 @@ int ensure_wavefront(rt_scene *s, uint32_t npix) {
     if (s->wf.capacity == cap) return RT_OK;
     free_wavefront(s);
     rt::WavefrontBuffers &w = s->wf;
-    RT_HIP(dev_alloc(s, &w.ray, (size_t)cap * 6));
-    RT_HIP(dev_alloc(s, &w.thr, (size_t)cap * 3));
-    RT_HIP(dev_alloc(s, &w.rad, (size_t)cap * 3));
-    RT_HIP(dev_alloc(s, &w.rng, (size_t)cap));
-    RT_HIP(dev_alloc(s, &w.meta, (size_t)cap));
-    RT_HIP(dev_alloc(s, &w.hit_t, (size_t)cap));
-    RT_HIP(dev_alloc(s, &w.hit_tri, (size_t)cap));
+    RT_HIP(dev_alloc(s, &w.ray, (size_t)cap * 2));
+    RT_HIP(dev_alloc(s, &w.state, (size_t)cap * 2));
     RT_HIP(dev_alloc(s, &w.queue[0], (size_t)cap));
     RT_HIP(dev_alloc(s, &w.queue[1], (size_t)cap));
     RT_HIP(dev_alloc(s, &w.qcount, (size_t)4));

@@ -212,10 +212,8 @@ __global__ __launch_bounds__(kBlock) void k_render_replay(DevScene S, rt::Render
 // spp0 + i / npix.
 // ---------------------------------------------------------------------------------------------
 struct WfView {
-    float *ray, *thr, *rad;
-    uint32_t *rng, *meta;
-    float *hit_t;
-    int32_t *hit_tri;
+    float4 *ray;    // [2i] = (o.xyz, d.x)  [2i+1] = (d.y, d.z, hit t, bits(hit triangle))
+    float4 *state;  // [2i] = (throughput.xyz, bits(rng))  [2i+1] = (radiance.xyz, bits(depth left))
     uint32_t cap;
 };
 
@@ -227,20 +225,10 @@ __global__ __launch_bounds__(kBlock) void wf_generate(DevScene S, rt::RenderPara
         const uint32_t px = pix % rp.W, py = pix / rp.W;
         uint32_t rng = rng_seed(counter_seed(pix, sample, rp.seed));
         const v3 d = primary_direction(S, px, py, rp.W, rp.H, rng);
-        V.ray[i] = S.cam_pos[0];
-        V.ray[V.cap + i] = S.cam_pos[1];
-        V.ray[2 * (size_t)V.cap + i] = S.cam_pos[2];
-        V.ray[3 * (size_t)V.cap + i] = d.x;
-        V.ray[4 * (size_t)V.cap + i] = d.y;
-        V.ray[5 * (size_t)V.cap + i] = d.z;
-        V.thr[i] = 1.f;
-        V.thr[V.cap + i] = 1.f;
-        V.thr[2 * (size_t)V.cap + i] = 1.f;
-        V.rad[i] = 0.f;
-        V.rad[V.cap + i] = 0.f;
-        V.rad[2 * (size_t)V.cap + i] = 0.f;
-        V.rng[i] = rng;
-        V.meta[i] = rp.max_depth;
+        V.ray[2 * (size_t)i] = make_float4(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2], d.x);
+        V.ray[2 * (size_t)i + 1] = make_float4(d.y, d.z, 0.f, 0.f);
+        V.state[2 * (size_t)i] = make_float4(1.f, 1.f, 1.f, __uint_as_float(rng));
+        V.state[2 * (size_t)i + 1] = make_float4(0.f, 0.f, 0.f, __uint_as_float(rp.max_depth));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         qcount[0] = npaths;
@@ -276,8 +264,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
     TraceStats st{0, 0, 0, 0};
     for (;;) {
         if (hasRay && T.done()) {
-            V.hit_t[slot] = T.tBest;
-            V.hit_tri[slot] = T.triBest;
+            reinterpret_cast<float2 *>(V.ray + 2 * (size_t)slot + 1)[1] = make_float2(T.tBest, __int_as_float(T.triBest));
             hasRay = false;
             ++segs;
         }
@@ -304,10 +291,8 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
                 if (!hasRay && rank >= given && rank < given + take) {
                     const uint32_t j = chunkNext + (rank - given);
                     slot = queue ? queue[j] : j;
-                    const v3 o = mk(V.ray[slot], V.ray[V.cap + slot], V.ray[2 * (size_t)V.cap + slot]);
-                    const v3 d = mk(V.ray[3 * (size_t)V.cap + slot], V.ray[4 * (size_t)V.cap + slot],
-                                    V.ray[5 * (size_t)V.cap + slot]);
-                    T.start(S, o, d);
+                    const float4 r0 = V.ray[2 * (size_t)slot], r1 = V.ray[2 * (size_t)slot + 1];
+                    T.start(S, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y));
                     hasRay = true;
                 }
                 chunkNext += take;
@@ -353,29 +338,21 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const u
         uint32_t i = 0;
         if (j < count) {
             i = queue ? queue[j] : j;
+            const float4 r0 = V.ray[2 * (size_t)i], r1 = V.ray[2 * (size_t)i + 1];
+            const float4 s0 = V.state[2 * (size_t)i], s1 = V.state[2 * (size_t)i + 1];
             PathState P;
-            P.o = mk(V.ray[i], V.ray[V.cap + i], V.ray[2 * (size_t)V.cap + i]);
-            P.d = mk(V.ray[3 * (size_t)V.cap + i], V.ray[4 * (size_t)V.cap + i], V.ray[5 * (size_t)V.cap + i]);
-            P.T = mk(V.thr[i], V.thr[V.cap + i], V.thr[2 * (size_t)V.cap + i]);
-            P.L = mk(V.rad[i], V.rad[V.cap + i], V.rad[2 * (size_t)V.cap + i]);
-            P.rng = V.rng[i];
-            P.depth = V.meta[i];
-            alive = shade_hit(S, LC, P, V.hit_t[i], V.hit_tri[i], lightTests);
-            V.rad[i] = P.L.x;
-            V.rad[V.cap + i] = P.L.y;
-            V.rad[2 * (size_t)V.cap + i] = P.L.z;
+            P.o = mk(r0.x, r0.y, r0.z);
+            P.d = mk(r0.w, r1.x, r1.y);
+            P.T = mk(s0.x, s0.y, s0.z);
+            P.L = mk(s1.x, s1.y, s1.z);
+            P.rng = __float_as_uint(s0.w);
+            P.depth = __float_as_uint(s1.w);
+            alive = shade_hit(S, LC, P, r1.z, __float_as_int(r1.w), lightTests);
+            V.state[2 * (size_t)i + 1] = make_float4(P.L.x, P.L.y, P.L.z, __uint_as_float(P.depth));
             if (alive) {
-                V.ray[i] = P.o.x;
-                V.ray[V.cap + i] = P.o.y;
-                V.ray[2 * (size_t)V.cap + i] = P.o.z;
-                V.ray[3 * (size_t)V.cap + i] = P.d.x;
-                V.ray[4 * (size_t)V.cap + i] = P.d.y;
-                V.ray[5 * (size_t)V.cap + i] = P.d.z;
-                V.thr[i] = P.T.x;
-                V.thr[V.cap + i] = P.T.y;
-                V.thr[2 * (size_t)V.cap + i] = P.T.z;
-                V.rng[i] = P.rng;
-                V.meta[i] = P.depth;
+                V.ray[2 * (size_t)i] = make_float4(P.o.x, P.o.y, P.o.z, P.d.x);
+                V.ray[2 * (size_t)i + 1] = make_float4(P.d.y, P.d.z, 0.f, 0.f);
+                V.state[2 * (size_t)i] = make_float4(P.T.x, P.T.y, P.T.z, __uint_as_float(P.rng));
             }
         }
         const unsigned long long mask = __ballot(alive);
@@ -408,7 +385,8 @@ __global__ __launch_bounds__(kBlock) void wf_accumulate(WfView V, uint32_t npix,
         v3 acc = first ? mk(0.f, 0.f, 0.f) : mk(sum[3 * (size_t)pix], sum[3 * (size_t)pix + 1], sum[3 * (size_t)pix + 2]);
         for (uint32_t s = 0; s < nslots; ++s) {
             const size_t i = (size_t)s * npix + pix;
-            acc = acc + mk(V.rad[i], V.rad[V.cap + i], V.rad[2 * (size_t)V.cap + i]);
+            const float4 l = V.state[2 * i + 1];
+            acc = acc + mk(l.x, l.y, l.z);
         }
         sum[3 * (size_t)pix] = acc.x;
         sum[3 * (size_t)pix + 1] = acc.y;
@@ -484,7 +462,7 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
                                    const WavefrontBuffers &wb, bool count, hipStream_t stream, KernelTimer &timer) {
     const uint32_t npix = rp.W * rp.H;
     const uint32_t slots = wb.capacity / npix;  // samples in flight per pass (host guarantees >= 1)
-    WfView V{wb.ray, wb.thr, wb.rad, wb.rng, wb.meta, wb.hit_t, wb.hit_tri, wb.capacity};
+    WfView V{wb.ray, wb.state, wb.capacity};
     uint32_t done = 0;
     bool first = true;
     while (done < rp.spp_count) {

@@ -79,17 +79,14 @@ struct RenderParams {
     uint32_t seed;
 };
 
-// Scratch of the wavefront pipeline: SoA path records for `capacity` paths, two index queues,
-// queue counters.  Owned by the scene, sized on first use.
+// Scratch of the wavefront pipeline: path records for `capacity` paths (64 B each, as four 16-byte
+// quarters so that a lane moves a record with four loads or stores: the vector-memory path charges
+// per lane and instruction, not per byte), two index queues, queue counters.  Owned by the scene,
+// sized on first use.
 struct WavefrontBuffers {
     uint32_t capacity = 0;
-    float *ray = nullptr;       // 6 x capacity: ox, oy, oz, dx, dy, dz (one array per component)
-    float *thr = nullptr;       // 3 x capacity: throughput
-    float *rad = nullptr;       // 3 x capacity: radiance gathered by the sample in flight
-    uint32_t *rng = nullptr;    // capacity: engine state
-    uint32_t *meta = nullptr;   // capacity: depth left
-    float *hit_t = nullptr;     // capacity
-    int32_t *hit_tri = nullptr; // capacity
+    float4 *ray = nullptr;    // 2 x capacity: [2i] = (o.xyz, d.x)  [2i+1] = (d.y, d.z, hit t, bits(hit triangle))
+    float4 *state = nullptr;  // 2 x capacity: [2i] = (throughput.xyz, bits(rng))  [2i+1] = (radiance.xyz, bits(depth left))
     uint32_t *queue[2] = {nullptr, nullptr};  // path indices alive in the current / next bounce
     uint32_t *qcount = nullptr; // [0], [1]: queue lengths (device), [2..]: spare
 };
