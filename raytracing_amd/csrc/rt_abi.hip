@@ -200,6 +200,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     v.mats = s->d_mats;
     v.counters = s->d_counters;
     v.nlights = (uint32_t)f.lights.size();
+    v.nmats = (uint32_t)mats.size();
     for (int k = 0; k < 3; ++k) {
         v.grid_origin[k] = f.grid_origin[k];
         v.grid_cell[k] = f.grid_cell[k];

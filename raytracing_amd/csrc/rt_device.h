@@ -149,7 +149,7 @@ struct DevScene {
     const uint32_t *lights;   // leaf-order positions of the emissive triangles
     const DevMaterial *mats;
     unsigned long long *counters;  // kCounterShards x kCounterStride; per shard [0] segments [1] nodes [2] tri tests [3] light tests
-    uint32_t nlights;
+    uint32_t nlights, nmats;
     float grid_origin[3], grid_cell[3];  // node-box plane = origin + q * cell, q a 16-bit integer
     float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];
     float tan_x, tan_y;
@@ -410,20 +410,36 @@ struct PathState {
 // every diffuse vertex tests its new direction against ALL lights (light_pdf below), the same few
 // records for every lane, and fetching them through the vector-memory path was more than half of
 // the shading kernel's load instructions.
+// The material table's first kLdsMats entries ride along (two 16-byte gathers per vertex otherwise).
 constexpr uint32_t kLdsLights = 64;
+constexpr uint32_t kLdsMats = 64;
 struct LightCache {
     const float4 *recs;  // LDS: 4 x float4 per cached light, light-list order
     const int *ids;      // LDS: leaf-order triangle position of each cached light
+    const float4 *mats;  // LDS: 2 x float4 per cached material
     uint32_t n;          // lights cached: min(S.nlights, kLdsLights)
+    uint32_t nm;         // materials cached: min(S.nmats, kLdsMats)
+};
+struct LightCacheStorage {
+    float4 recs[4 * kLdsLights];
+    float4 mats[2 * kLdsMats];
+    int ids[kLdsLights];
 };
 
 // Call from all threads of the workgroup; ends with a barrier.
-__device__ __forceinline__ LightCache load_light_cache(const DevScene &S, float4 *recs, int *ids) {
+__device__ __forceinline__ LightCache load_light_cache(const DevScene &S, LightCacheStorage &st) {
     const uint32_t n = S.nlights < kLdsLights ? S.nlights : kLdsLights;
-    for (uint32_t e = threadIdx.x; e < 4u * n; e += kBlock) recs[e] = S.tris[4 * (size_t)S.lights[e >> 2] + (e & 3u)];
-    for (uint32_t k = threadIdx.x; k < n; k += kBlock) ids[k] = (int)S.lights[k];
+    const uint32_t nm = S.nmats < kLdsMats ? S.nmats : kLdsMats;
+    for (uint32_t e = threadIdx.x; e < 4u * n; e += kBlock) st.recs[e] = S.tris[4 * (size_t)S.lights[e >> 2] + (e & 3u)];
+    for (uint32_t e = threadIdx.x; e < 2u * nm; e += kBlock) st.mats[e] = reinterpret_cast<const float4 *>(S.mats)[e];
+    for (uint32_t k = threadIdx.x; k < n; k += kBlock) st.ids[k] = (int)S.lights[k];
     __syncthreads();
-    return LightCache{recs, ids, n};
+    return LightCache{st.recs, st.ids, st.mats, n, nm};
+}
+
+__device__ __forceinline__ DevMaterial material(const DevScene &S, const LightCache &LC, uint32_t m) {
+    if (m < LC.nm) return DevMaterial{LC.mats[2 * m], LC.mats[2 * m + 1]};
+    return S.mats[m];
 }
 
 // Triangle::pdf (main.cpp:510-517) of a light triangle the ray x + t w hits
@@ -475,7 +491,7 @@ __device__ __forceinline__ bool sample_vertex(const DevScene &S, const LightCach
     V.mat = __float_as_uint(q3.y);
     V.op = kOpEmit;
     if (P.depth == 1) return false;   // main.cpp:1197
-    const DevMaterial M = S.mats[V.mat];
+    const DevMaterial M = material(S, LC, V.mat);
     const int type = __float_as_int(M.a.w);
 
     // Intersection::update (main.cpp:84-95) for the winning triangle
@@ -499,8 +515,13 @@ __device__ __forceinline__ bool sample_vertex(const DevScene &S, const LightCach
             w = mk(0.f, 0.f, 0.f);
         } else {
             const uint32_t k = rng_uint(P.rng, S.nlights);
-            const float4 *lp = S.tris + 4 * (size_t)S.lights[k];
-            const float4 l0 = lp[0], l1 = lp[1], l2 = lp[2];
+            float4 l0, l1, l2;
+            if (k < LC.n) {
+                l0 = LC.recs[4 * k], l1 = LC.recs[4 * k + 1], l2 = LC.recs[4 * k + 2];
+            } else {
+                const float4 *lp = S.tris + 4 * (size_t)S.lights[k];
+                l0 = lp[0], l1 = lp[1], l2 = lp[2];
+            }
             float u = rng_uniform(P.rng);  // Triangle::samplePoint, main.cpp:500-508
             float v = rng_uniform(P.rng);
             if (u + v > 1.f) {
@@ -557,9 +578,9 @@ __device__ __forceinline__ bool sample_vertex(const DevScene &S, const LightCach
 }
 
 // Forward evaluation of one vertex: L += T * e, T *= k.
-__device__ __forceinline__ void fold_forward(const DevScene &S, PathState &P, const Vertex &V) {
+__device__ __forceinline__ void fold_forward(const DevScene &S, const LightCache &LC, PathState &P, const Vertex &V) {
     if (V.op == kOpNone) return;
-    const DevMaterial M = S.mats[V.mat];
+    const DevMaterial M = material(S, LC, V.mat);
     const v3 color = mk(M.a.x, M.a.y, M.a.z);
     P.L = P.L + P.T * mk(M.b.x, M.b.y, M.b.z);
     if (V.op == kOpDiffuse)
@@ -574,15 +595,16 @@ __device__ __forceinline__ bool shade_hit(const DevScene &S, const LightCache &L
                                           uint32_t &lightTests) {
     Vertex V;
     const bool alive = sample_vertex(S, LC, P, t, tri, V, lightTests);
-    fold_forward(S, P, V);
+    fold_forward(S, LC, P, V);
     return alive;
 }
 
 // Backward evaluation of one vertex in the reference's operation order: returns this vertex's
 // radiance given the radiance `l` that came back along its continuation ray.
-__device__ __forceinline__ v3 fold_backward(const DevScene &S, int op, uint32_t mat, float wn, float pdf, v3 l) {
+__device__ __forceinline__ v3 fold_backward(const DevScene &S, const LightCache &LC, int op, uint32_t mat, float wn,
+                                            float pdf, v3 l) {
     if (op == kOpNone) return mk(0.f, 0.f, 0.f);
-    const DevMaterial M = S.mats[mat];
+    const DevMaterial M = material(S, LC, mat);
     const v3 color = mk(M.a.x, M.a.y, M.a.z);
     const v3 e = mk(M.b.x, M.b.y, M.b.z);
     if (op == kOpEmit) return e;

@@ -102,9 +102,8 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, uint32_t W, uint
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_render_mega(DevScene S, rt::RenderParams rp, float *__restrict__ sum) {
     __shared__ int s_stack[kStack * kBlock];
-    __shared__ float4 s_lrec[4 * rtd::kLdsLights];
-    __shared__ int s_lid[rtd::kLdsLights];
-    const LightCache LC = load_light_cache(S, s_lrec, s_lid);
+    __shared__ LightCacheStorage s_lights;
+    const LightCache LC = load_light_cache(S, s_lights);
     uint32_t px, py;
     if (!tile_pixel(rp.W, rp.H, px, py)) return;
     const uint32_t pix = py * rp.W + px;
@@ -157,9 +156,8 @@ template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_render_replay(DevScene S, rt::RenderParams rp, float *__restrict__ sum,
                                                           uint32_t *__restrict__ rec, uint32_t stride) {
     __shared__ int s_stack[kStack * kBlock];
-    __shared__ float4 s_lrec[4 * rtd::kLdsLights];
-    __shared__ int s_lid[rtd::kLdsLights];
-    const LightCache LC = load_light_cache(S, s_lrec, s_lid);
+    __shared__ LightCacheStorage s_lights;
+    const LightCache LC = load_light_cache(S, s_lights);
     uint32_t px, py;
     if (!tile_pixel(rp.W, rp.H, px, py)) return;
     const uint32_t pix = py * rp.W + px;
@@ -196,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void k_render_replay(DevScene S, rt::Render
         for (uint32_t k = nrec; k-- > 0;) {
             const uint32_t *r = rec + (size_t)k * 3u * stride + g;
             const uint32_t w0 = r[0];
-            l = fold_backward(S, (int)(w0 & 7u), w0 >> 3, __uint_as_float(r[stride]), __uint_as_float(r[2 * (size_t)stride]), l);
+            l = fold_backward(S, LC, (int)(w0 & 7u), w0 >> 3, __uint_as_float(r[stride]), __uint_as_float(r[2 * (size_t)stride]), l);
         }
         acc = acc + l;  // color += generateSample(...), main.cpp:1224
     }
@@ -320,9 +318,8 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const u
                                                     uint32_t *__restrict__ cursor) {
     __shared__ uint32_t s_buf[kAppendBuf];
     __shared__ uint32_t s_count, s_base;
-    __shared__ float4 s_lrec[4 * rtd::kLdsLights];
-    __shared__ int s_lid[rtd::kLdsLights];
-    const LightCache LC = load_light_cache(S, s_lrec, s_lid);
+    __shared__ LightCacheStorage s_lights;
+    const LightCache LC = load_light_cache(S, s_lights);
     const uint32_t count = *qcount_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) *cursor = 0u;  // work cursor of the next extend pass
     if (threadIdx.x == 0) s_count = 0u;
