@@ -17,7 +17,8 @@ i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE" \
             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum" \
             "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
-            "TA_TA_BUSY_sum TA_BUSY_avr TD_TD_BUSY_sum TD_TC_STALL_sum TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum"; do
+            "TA_TA_BUSY_sum TA_BUSY_avr TD_TD_BUSY_sum TD_TC_STALL_sum TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum" \
+            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_BRANCH TCP_TCP_LATENCY_sum TCP_TA_TCP_STATE_READ_sum"; do
   i=$((i+1))
   timeout -s KILL 600 rocprofv3 --pmc $ctrs --output-format csv -d $out/pmc$i -- python3 $root/bench.py --steps 1 --warmup 0 --spp-per-gpu 16 --no-cpu-baseline --no-primary "$@" > $out/pmc$i.log 2>&1
 done
