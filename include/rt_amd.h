@@ -59,7 +59,7 @@ extern "C" {
 /* Pipelines of rt_render*: both produce the same estimator.
  * RT_PIPE_MEGAKERNEL: one persistent thread per pixel, a lane starts its next sample as soon
  * as its path ends.  RT_PIPE_WAVEFRONT: queue-per-bounce kernels (generate / trace / shade)
- * over SoA ray and hit buffers with wave-level compaction; needs RT_RNG_COUNTER. */
+ * over 64-byte path records and index queues; needs RT_RNG_COUNTER. */
 #define RT_PIPE_MEGAKERNEL 0
 #define RT_PIPE_WAVEFRONT 1
 
@@ -103,7 +103,7 @@ typedef struct rt_host_scene rt_host_scene; /* parsed scene file, host memory on
 typedef struct rt_scene_stats {
     uint32_t ntri;
     uint32_t nlights;
-    uint32_t nnodes;      /* 64-byte two-child nodes */
+    uint32_t nnodes;      /* 32-byte two-child nodes */
     uint32_t tree_height; /* inner-node levels on the longest root-to-leaf path */
     double build_seconds; /* host BVH build + flatten */
     uint64_t device_bytes;

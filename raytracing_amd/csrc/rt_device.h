@@ -1,7 +1,7 @@
 // rt_device.h -- device-side building blocks of the gfx950 path tracer: fp32 vector math in
 // the reference's operation order, the minstd_rand / libstdc++ distribution restatements, the
 // exact-arithmetic ray/triangle test, the conservative ray/box slab test, stack traversal of
-// the 64-byte two-child BVH nodes, and one shading step of the reference's estimator.
+// the 32-byte two-child BVH nodes, and one shading step of the reference's estimator.
 //
 // Everything here is compiled with -ffp-contract=off: results that decide which triangle a ray
 // hits must not depend on fused multiply-adds, because the reference is built for x86-64
@@ -224,7 +224,9 @@ struct Traversal {
     struct f2 {
         float x, y;
     };
-    v3 o, d, ga, gb;  // origin, direction, cell/d, (grid origin - o)/d: plane distance t = q * ga + gb
+    v3 o, d;       // origin, direction
+    v3 ga, gn, gf; // plane distance t = q * ga + g: ga = cell/d, g = (grid origin - o)/d, moved towards the
+                   // ray origin for near planes (gn) and away from it for far planes (gf) by the rounding bound
     uint32_t rx, ry, rz;  // 16 where the direction component is negative (the near plane is the high one), else 0
     float tBest;
     int triBest;
@@ -247,7 +249,17 @@ struct Traversal {
         d = rd;
         const v3 r = mk(recip_clamped(rd.x), recip_clamped(rd.y), recip_clamped(rd.z));
         ga = mk(S.grid_cell[0] * r.x, S.grid_cell[1] * r.y, S.grid_cell[2] * r.z);
-        gb = mk((S.grid_origin[0] - ro.x) * r.x, (S.grid_origin[1] - ro.y) * r.y, (S.grid_origin[2] - ro.z) * r.z);
+        const v3 go = mk(S.grid_origin[0] - ro.x, S.grid_origin[1] - ro.y, S.grid_origin[2] - ro.z);
+        const v3 gb = mk(go.x * r.x, go.y * r.y, go.z * r.z);
+        // Rounding of go, gb, ga and of the FMA itself displaces a plane by at most
+        // |r| (1.5 |go| + extent) 2^-23 in t; four times that is taken off near planes and added to far
+        // ones, so a far-away ray origin (large |go|) cannot produce a false miss.  65000 cells = extent.
+        const float k = 4.76837158e-7f;  // 2^-21
+        const v3 dl = mk(__builtin_fabsf(r.x) * (__builtin_fabsf(go.x) + 65000.f * S.grid_cell[0]) * k,
+                         __builtin_fabsf(r.y) * (__builtin_fabsf(go.y) + 65000.f * S.grid_cell[1]) * k,
+                         __builtin_fabsf(r.z) * (__builtin_fabsf(go.z) + 65000.f * S.grid_cell[2]) * k);
+        gn = gb - dl;
+        gf = gb + dl;
         rx = (__float_as_uint(ga.x) >> 31) << 4;
         ry = (__float_as_uint(ga.y) >> 31) << 4;
         rz = (__float_as_uint(ga.z) >> 31) << 4;
@@ -277,9 +289,9 @@ struct Traversal {
     // One axis of one child box, word = lo | hi << 16: rotating the word by 16 bits for a negative
     // direction puts the near plane in the low half, so no min/max per axis is needed.  Returns the
     // (near, far) plane distances.  Two scalar FMAs: v_pk_fma_f32 measured 4 % slower here.
-    static __device__ __forceinline__ f2 slab(uint32_t w, uint32_t rot, float a, float b) {
+    static __device__ __forceinline__ f2 slab(uint32_t w, uint32_t rot, float a, float bn, float bf) {
         const uint32_t u = __builtin_amdgcn_alignbit(w, w, rot);
-        return f2{__builtin_fmaf((float)(u & 0xffffu), a, b), __builtin_fmaf((float)(u >> 16), a, b)};
+        return f2{__builtin_fmaf((float)(u & 0xffffu), a, bn), __builtin_fmaf((float)(u >> 16), a, bf)};
     }
 
     // One round: walk inner nodes until this lane holds a leaf (or has nothing left), then test
@@ -294,8 +306,10 @@ struct Traversal {
             // outward and added two guard cells per side, far more than the rounding of these FMAs
             // (a few ulps of the scene's extent), so no box is thinner than four cells and plain
             // near <= far needs no tolerance.  x = near plane, y = far plane after the rotation.
-            const f2 lx = slab(n0.x, rx, ga.x, gb.x), ly = slab(n0.y, ry, ga.y, gb.y), lz = slab(n0.z, rz, ga.z, gb.z);
-            const f2 qx = slab(n0.w, rx, ga.x, gb.x), qy = slab(n1.x, ry, ga.y, gb.y), qz = slab(n1.y, rz, ga.z, gb.z);
+            const f2 lx = slab(n0.x, rx, ga.x, gn.x, gf.x), ly = slab(n0.y, ry, ga.y, gn.y, gf.y),
+                     lz = slab(n0.z, rz, ga.z, gn.z, gf.z);
+            const f2 qx = slab(n0.w, rx, ga.x, gn.x, gf.x), qy = slab(n1.x, ry, ga.y, gn.y, gf.y),
+                     qz = slab(n1.y, rz, ga.z, gn.z, gf.z);
             const float tnL = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(lx.x, ly.x), lz.x), 0.f);
             const float tfL = __builtin_fminf(__builtin_fminf(__builtin_fminf(lx.y, ly.y), lz.y), tBest);
             const float tnR = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(qx.x, qy.x), qz.x), 0.f);

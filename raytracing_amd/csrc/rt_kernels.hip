@@ -6,7 +6,7 @@
 //   k_render_mega    persistent lane per pixel, path regeneration     (generatePixel's loop, main.cpp:1220-1225)
 //   k_render_replay  the reference's RNG stream and recursion order, bit-exact validation kernel
 //   wf_generate / wf_extend / wf_shade / wf_accumulate
-//                    the same estimator as queue-per-bounce kernels over SoA path records
+//                    the same estimator as queue-per-bounce kernels over 64-byte path records
 //   k_tonemap        mean, ACES, gamma, byte conversion               (main.cpp:1226-1231, 840-846)
 //
 // Pixel kernels map a wave to an 8x8 pixel tile (coherent primary rays) and a workgroup to a
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void k_render_replay(DevScene S, rt::Render
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wavefront pipeline.  Path record i lives at slot i of every SoA array for its whole life;
+// Wavefront pipeline.  Path record i lives at slot i of the record arrays for its whole life;
 // queues hold the slot indices still alive.  Slot i renders pixel i % npix, sample
 // spp0 + i / npix.
 // ---------------------------------------------------------------------------------------------

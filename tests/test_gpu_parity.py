@@ -76,6 +76,26 @@ def test_random_rays_bit_exact(scene_dir, oracle_mod):
     _compare_hits(ids_g, t_g, ids_o, t_o, tie)
 
 
+def test_far_origin_rays_bit_exact(scene_dir, oracle_mod):
+    """Ray origins 10 to 5000 scene extents away (the box test's rounding grows with the distance between
+    the origin and the node grid; it widens its slabs accordingly) and rays aimed along box faces."""
+    host, gpu, orc = _load(scene_dir, oracle_mod, "cornell", 64, 64)
+    rng = np.random.RandomState(19)
+    n = 20000
+    target = rng.uniform(-1.0, 1.0, size=(n, 3)).astype(np.float32)
+    target[: n // 4, rng.randint(0, 3)] = np.float32(1.0)          # points on a wall plane
+    away = rng.normal(size=(n, 3))
+    away /= np.linalg.norm(away, axis=1, keepdims=True)
+    dist = (10.0 ** rng.uniform(1.3, 3.9, size=(n, 1)))            # 20 .. 8000 units; the box is 2 wide
+    o = (target + away * dist).astype(np.float32)
+    d = (target - o).astype(np.float64)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    ids_o, t_o, tie, _ = orc.intersect(o, d, use_bvh=False)
+    ids_g, t_g = gpu.intersect(o, d)
+    _compare_hits(ids_g, t_g, ids_o, t_o, tie)
+    assert (ids_g != 0xFFFFFFFF).sum() > 0.5 * n
+
+
 def test_axis_parallel_rays_are_finite(scene_dir, oracle_mod):
     """Rays exactly parallel to a triangle's plane make the reference's 3x3 inverse divide by a
     zero determinant; it then accepts a NaN-distance "hit" whenever that triangle is the first
