@@ -30,6 +30,7 @@ WORKLOADS = {
     "spheres1m": ("spheres1m", {}, 1920, 1080, 128, 8),
     "cornell": ("cornell", {}, 1920, 1080, 256, 8),
     "glass4k": ("glass", {"grid": 6, "subdiv": 5}, 3840, 2160, 64, 16),
+    "emissive": ("emissive", {"subdiv": 4, "lamps": 3}, 1920, 1080, 16, 8),   # 15 360 light triangles
 }
 
 

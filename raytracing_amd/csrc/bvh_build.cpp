@@ -212,24 +212,15 @@ uint32_t height_of(const std::vector<BNode> &nodes, int32_t ref) {
     return 1 + std::max(height_of(nodes, nodes[ref].child[0]), height_of(nodes, nodes[ref].child[1]));
 }
 
-}  // namespace
 
-void build_flat_scene(const rt_scene_desc &desc, FlatScene &out) {
-    auto t0 = std::chrono::steady_clock::now();
-    const uint32_t n = desc.ntri;
-    if (n >= kMaxTriangles) throw std::runtime_error("too many triangles (limit 2^28 - 1)");
-    if (n && (!desc.tri_verts || !desc.tri_material)) throw std::runtime_error("null triangle arrays");
-    if (desc.nmat && !desc.materials) throw std::runtime_error("null material table");
-    for (uint32_t i = 0; i < n; ++i)
-        if (desc.tri_material[i] >= desc.nmat) throw std::runtime_error("triangle names a missing material");
-    for (size_t i = 0; i < (size_t)n * 9; ++i)
-        if (!std::isfinite(desc.tri_verts[i])) throw std::runtime_error("non-finite vertex coordinate");
-
+// Builds the tree over triangles which[0..n) of `verts` (9 floats each; which == nullptr: triangles
+// 0..n-1) and flattens it.  out.order[k] = position in `which` of the triangle at leaf position k.
+void build_tree(const float *verts, const uint32_t *which, uint32_t n, FlatTree &out) {
     Builder B;
     B.prims.resize(n);
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < (int64_t)n; ++i) {
-        const float *v = desc.tri_verts + 9 * i;
+        const float *v = verts + 9 * (size_t)(which ? which[i] : (uint32_t)i);
         Prim &p = B.prims[i];
         p.box.reset();
         p.box.grow(v);
@@ -243,7 +234,7 @@ void build_flat_scene(const rt_scene_desc &desc, FlatScene &out) {
     B.nodes.resize(std::max<uint32_t>(n, 1));
     uint32_t root = B.alloc();
     Box never;
-    for (int k = 0; k < 3; ++k) never.lo[k] = never.hi[k] = 3.0e30f;  // a far-away point: always culled
+    for (int k = 0; k < 3; ++k) never.lo[k] = never.hi[k] = 3.0e30f;  // marks an absent child
     if (n <= kMaxLeafTris) {
         BNode &nd = B.nodes[root];
         nd.box[0] = n ? B.bounds(0, n) : never;
@@ -291,14 +282,15 @@ void build_flat_scene(const rt_scene_desc &desc, FlatScene &out) {
     for (uint32_t k = 0; k < nnodes; ++k) newIndex[order[k]] = k;
 
     out.nnodes = nnodes;
-    out.ntri = n;
-    out.tree_height = height;
+    out.height = height;
+    out.order.resize(n);
+    for (uint32_t k = 0; k < n; ++k) out.order[k] = B.prims[k].id;
 
-    // Node boxes go to the device on a 16-bit grid spanning the (padded) scene bounds:
+    // Node boxes go to the device on a 16-bit grid spanning the (padded) bounds of the triangles:
     //   plane = grid_origin + q * grid_cell,  q in [0, 65535],
     // rounded outward, plus two guard cells per side.  The kernels evaluate a plane distance as one FMA
-    // with per-ray constants cell/d and (origin - o)/d; its rounding error is a few ulps of the scene
-    // extent (about 1e-7 of it), the guard is two cells (3e-5 of it).
+    // with per-ray constants cell/d and (origin - o)/d and widen each slab by the rounding bound of that
+    // arithmetic; the guard cells are on top of it.
     auto real = [](const Box &b) { return b.lo[0] <= b.hi[0] && b.lo[0] < 1.0e30f; };
     float glo[3] = {3.0e30f, 3.0e30f, 3.0e30f}, ghi[3] = {-3.0e30f, -3.0e30f, -3.0e30f};
     for (uint32_t k = 0; k < nnodes; ++k)
@@ -345,27 +337,56 @@ void build_flat_scene(const rt_scene_desc &desc, FlatScene &out) {
             w[6 + c] = (uint32_t)(nd.child[c] >= 0 ? (int32_t)newIndex[nd.child[c]] : nd.child[c]);
         }
     }
+}
+
+// Triangle record (16 floats) of loader triangle `id`: Triangle::update (main.cpp:527-536).
+void triangle_record(const rt_scene_desc &desc, uint32_t id, float *q) {
+    const float *v = desc.tri_verts + 9 * (size_t)id;
+    hm::vec3 A = hm::V3(v[0], v[1], v[2]), Bv = hm::V3(v[3], v[4], v[5]), C = hm::V3(v[6], v[7], v[8]);
+    hm::vec3 AB = Bv - A, AC = C - A;
+    hm::vec3 N = hm::cross(AB, AC);
+    float pdfConst = 2.f / hm::length(N);
+    q[0] = A.x; q[1] = A.y; q[2] = A.z; q[3] = AB.x;
+    q[4] = AB.y; q[5] = AB.z; q[6] = AC.x; q[7] = AC.y;
+    q[8] = AC.z; q[9] = N.x; q[10] = N.y; q[11] = N.z;
+    q[12] = bits_to_float(id);
+    q[13] = bits_to_float(desc.tri_material[id]);
+    q[14] = pdfConst;
+    q[15] = 0.f;
+}
+
+}  // namespace
+
+void build_flat_scene(const rt_scene_desc &desc, FlatScene &out) {
+    auto t0 = std::chrono::steady_clock::now();
+    const uint32_t n = desc.ntri;
+    if (n >= kMaxTriangles) throw std::runtime_error("too many triangles (limit 2^28 - 1)");
+    if (n && (!desc.tri_verts || !desc.tri_material)) throw std::runtime_error("null triangle arrays");
+    if (desc.nmat && !desc.materials) throw std::runtime_error("null material table");
+    for (uint32_t i = 0; i < n; ++i)
+        if (desc.tri_material[i] >= desc.nmat) throw std::runtime_error("triangle names a missing material");
+    for (size_t i = 0; i < (size_t)n * 9; ++i)
+        if (!std::isfinite(desc.tri_verts[i])) throw std::runtime_error("non-finite vertex coordinate");
+
+    FlatTree tree;
+    build_tree(desc.tri_verts, nullptr, n, tree);
+    out.nnodes = tree.nnodes;
+    out.ntri = n;
+    out.tree_height = tree.height;
+    out.nodes.swap(tree.nodes);
+    for (int a = 0; a < 3; ++a) {
+        out.grid_origin[a] = tree.grid_origin[a];
+        out.grid_cell[a] = tree.grid_cell[a];
+    }
 
     // Triangles in leaf order, with the derived data of Triangle::update (main.cpp:527-536).
     out.tris.assign((size_t)std::max<uint32_t>(n, 1) * 16, 0.f);
     std::vector<uint32_t> posOfId(n);
 #pragma omp parallel for schedule(static)
     for (int64_t k = 0; k < (int64_t)n; ++k) {
-        const uint32_t id = B.prims[k].id;
+        const uint32_t id = tree.order[k];
         posOfId[id] = (uint32_t)k;
-        const float *v = desc.tri_verts + 9 * (size_t)id;
-        hm::vec3 A = hm::V3(v[0], v[1], v[2]), Bv = hm::V3(v[3], v[4], v[5]), C = hm::V3(v[6], v[7], v[8]);
-        hm::vec3 AB = Bv - A, AC = C - A;
-        hm::vec3 N = hm::cross(AB, AC);
-        float pdfConst = 2.f / hm::length(N);
-        float *q = &out.tris[(size_t)k * 16];
-        q[0] = A.x; q[1] = A.y; q[2] = A.z; q[3] = AB.x;
-        q[4] = AB.y; q[5] = AB.z; q[6] = AC.x; q[7] = AC.y;
-        q[8] = AC.z; q[9] = N.x; q[10] = N.y; q[11] = N.z;
-        q[12] = bits_to_float(id);
-        q[13] = bits_to_float(desc.tri_material[id]);
-        q[14] = pdfConst;
-        q[15] = 0.f;
+        triangle_record(desc, id, &out.tris[(size_t)k * 16]);
     }
     if (n == 0) {  // one never-hit dummy so leaf_ref(0, 1) stays in bounds
         float *q = &out.tris[0];
@@ -375,10 +396,37 @@ void build_flat_scene(const rt_scene_desc &desc, FlatScene &out) {
 
     // Light list in loader order (main.cpp:1096-1098): length(emission) > EPS.
     out.lights.clear();
+    std::vector<uint32_t> lightIds;
     for (uint32_t id = 0; id < n; ++id) {
         const rt_material &m = desc.materials[desc.tri_material[id]];
-        if (hm::length(hm::V3(m.emission[0], m.emission[1], m.emission[2])) > EPS) out.lights.push_back(posOfId[id]);
+        if (hm::length(hm::V3(m.emission[0], m.emission[1], m.emission[2])) > EPS) {
+            out.lights.push_back(posOfId[id]);
+            lightIds.push_back(id);
+        }
     }
+
+    // A second tree over the light triangles alone, for LightSurface::pdf (main.cpp:771-783) when the
+    // lights are too many to loop over.  Its records repeat the triangle data in that tree's leaf order;
+    // record word 12 = index in the light list, word 13 = leaf position in the main triangle array.
+    const uint32_t nl = (uint32_t)lightIds.size();
+    FlatTree ltree;
+    build_tree(desc.tri_verts, lightIds.data(), nl, ltree);
+    out.light_nodes.swap(ltree.nodes);
+    out.light_nnodes = ltree.nnodes;
+    out.light_height = ltree.height;
+    for (int a = 0; a < 3; ++a) {
+        out.light_grid_origin[a] = ltree.grid_origin[a];
+        out.light_grid_cell[a] = ltree.grid_cell[a];
+    }
+    out.light_recs.assign((size_t)std::max<uint32_t>(nl, 1) * 16, 0.f);
+    for (uint32_t k = 0; k < nl; ++k) {
+        const uint32_t li = ltree.order[k];
+        float *q = &out.light_recs[(size_t)k * 16];
+        triangle_record(desc, lightIds[li], q);
+        q[12] = bits_to_float(li);
+        q[13] = bits_to_float(out.lights[li]);
+    }
+    if (nl == 0) out.light_recs[0] = out.light_recs[1] = out.light_recs[2] = 3.0e30f;  // never hit
     out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 

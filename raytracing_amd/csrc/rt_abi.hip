@@ -25,6 +25,8 @@ struct rt_scene {
     uint4 *d_nodes = nullptr;
     float4 *d_tris = nullptr;
     uint32_t *d_lights = nullptr;
+    uint4 *d_lnodes = nullptr;
+    float4 *d_lrecs = nullptr;
     rtd::DevMaterial *d_mats = nullptr;
     unsigned long long *d_counters = nullptr;
     rt::WavefrontBuffers wf;
@@ -184,12 +186,16 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     RT_TRY(dev_alloc(s, &s->d_nodes, f.nodes.size() / 4));
     RT_TRY(dev_alloc(s, &s->d_tris, f.tris.size() / 4));
     RT_TRY(dev_alloc(s, &s->d_lights, f.lights.size()));
+    RT_TRY(dev_alloc(s, &s->d_lnodes, f.light_nodes.size() / 4));
+    RT_TRY(dev_alloc(s, &s->d_lrecs, f.light_recs.size() / 4));
     RT_TRY(dev_alloc(s, &s->d_mats, mats.size()));
     RT_TRY(dev_alloc(s, &s->d_counters, kCounterWords));
     RT_TRY(hipMemcpy(s->d_nodes, f.nodes.data(), f.nodes.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     RT_TRY(hipMemcpy(s->d_tris, f.tris.data(), f.tris.size() * sizeof(float), hipMemcpyHostToDevice));
     if (!f.lights.empty())
         RT_TRY(hipMemcpy(s->d_lights, f.lights.data(), f.lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    RT_TRY(hipMemcpy(s->d_lnodes, f.light_nodes.data(), f.light_nodes.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    RT_TRY(hipMemcpy(s->d_lrecs, f.light_recs.data(), f.light_recs.size() * sizeof(float), hipMemcpyHostToDevice));
     RT_TRY(hipMemcpy(s->d_mats, mats.data(), mats.size() * sizeof(rtd::DevMaterial), hipMemcpyHostToDevice));
     RT_TRY(hipMemset(s->d_counters, 0, kCounterWords * sizeof(unsigned long long)));
 #undef RT_TRY
@@ -197,6 +203,14 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     v.nodes = s->d_nodes;
     v.tris = s->d_tris;
     v.lights = s->d_lights;
+    v.lnodes = s->d_lnodes;
+    v.lrecs = s->d_lrecs;
+    {
+        // LightSurface::pdf loops over the lights (cached in LDS) up to this many; above, it walks the light tree
+        const char *e = std::getenv("RT_LIGHT_TREE_MIN");
+        const long minLights = e ? std::atol(e) : (long)rtd::kLdsLights + 1;
+        v.light_tree = (long)f.lights.size() >= minLights && !f.lights.empty() ? 1u : 0u;
+    }
     v.mats = s->d_mats;
     v.counters = s->d_counters;
     v.nlights = (uint32_t)f.lights.size();
@@ -204,6 +218,8 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     for (int k = 0; k < 3; ++k) {
         v.grid_origin[k] = f.grid_origin[k];
         v.grid_cell[k] = f.grid_cell[k];
+        v.lgrid_origin[k] = f.light_grid_origin[k];
+        v.lgrid_cell[k] = f.light_grid_cell[k];
         v.cam_pos[k] = desc->camera.position[k];
         v.cam_right[k] = desc->camera.right[k];
         v.cam_up[k] = desc->camera.up[k];
@@ -224,6 +240,8 @@ void rt_scene_destroy(rt_scene *s) {
     (void)hipFree(s->d_nodes);
     (void)hipFree(s->d_tris);
     (void)hipFree(s->d_lights);
+    (void)hipFree(s->d_lnodes);
+    (void)hipFree(s->d_lrecs);
     (void)hipFree(s->d_mats);
     (void)hipFree(s->d_counters);
     delete s;

@@ -146,11 +146,15 @@ struct DevMaterial {
 struct DevScene {
     const uint4 *nodes;       // 2 x uint4 per node: 16-bit grid boxes of both children + two references
     const float4 *tris;       // 4 x float4 per triangle, leaf order
+    const uint4 *lnodes;      // tree over the light triangles only (same node format, own grid)
+    const float4 *lrecs;      // 4 x float4 per light in that tree's leaf order; q3 = (bits(light index), bits(leaf position), pdfConst, 0)
     const uint32_t *lights;   // leaf-order positions of the emissive triangles
     const DevMaterial *mats;
     unsigned long long *counters;  // kCounterShards x kCounterStride; per shard [0] segments [1] nodes [2] tri tests [3] light tests
     uint32_t nlights, nmats;
+    uint32_t light_tree;                 // nonzero: the launchers pick the kernels whose light_pdf walks lnodes
     float grid_origin[3], grid_cell[3];  // node-box plane = origin + q * cell, q a 16-bit integer
+    float lgrid_origin[3], lgrid_cell[3];  // the same for lnodes
     float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];
     float tan_x, tan_y;
 };
@@ -244,20 +248,21 @@ struct Traversal {
         if (__builtin_fabsf(v) < 1.0e-30f) v = __builtin_copysignf(1.0e-30f, v);
         return 1.f / v;
     }
-    __device__ __forceinline__ void start(const DevScene &S, v3 ro, v3 rd) {
+    __device__ __forceinline__ void start(const DevScene &S, v3 ro, v3 rd) { setup(S.grid_origin, S.grid_cell, ro, rd); }
+    __device__ __forceinline__ void setup(const float *origin, const float *cell, v3 ro, v3 rd) {
         o = ro;
         d = rd;
         const v3 r = mk(recip_clamped(rd.x), recip_clamped(rd.y), recip_clamped(rd.z));
-        ga = mk(S.grid_cell[0] * r.x, S.grid_cell[1] * r.y, S.grid_cell[2] * r.z);
-        const v3 go = mk(S.grid_origin[0] - ro.x, S.grid_origin[1] - ro.y, S.grid_origin[2] - ro.z);
+        ga = mk(cell[0] * r.x, cell[1] * r.y, cell[2] * r.z);
+        const v3 go = mk(origin[0] - ro.x, origin[1] - ro.y, origin[2] - ro.z);
         const v3 gb = mk(go.x * r.x, go.y * r.y, go.z * r.z);
         // Rounding of go, gb, ga and of the FMA itself displaces a plane by at most
         // |r| (1.5 |go| + extent) 2^-23 in t; four times that is taken off near planes and added to far
         // ones, so a far-away ray origin (large |go|) cannot produce a false miss.  65000 cells = extent.
         const float k = 4.76837158e-7f;  // 2^-21
-        const v3 dl = mk(__builtin_fabsf(r.x) * (__builtin_fabsf(go.x) + 65000.f * S.grid_cell[0]) * k,
-                         __builtin_fabsf(r.y) * (__builtin_fabsf(go.y) + 65000.f * S.grid_cell[1]) * k,
-                         __builtin_fabsf(r.z) * (__builtin_fabsf(go.z) + 65000.f * S.grid_cell[2]) * k);
+        const v3 dl = mk(__builtin_fabsf(r.x) * (__builtin_fabsf(go.x) + 65000.f * cell[0]) * k,
+                         __builtin_fabsf(r.y) * (__builtin_fabsf(go.y) + 65000.f * cell[1]) * k,
+                         __builtin_fabsf(r.z) * (__builtin_fabsf(go.z) + 65000.f * cell[2]) * k);
         gn = gb - dl;
         gf = gb + dl;
         rx = (__float_as_uint(ga.x) >> 31) << 4;
@@ -433,6 +438,7 @@ struct LightCache {
     const float4 *mats;  // LDS: 2 x float4 per cached material
     uint32_t n;          // lights cached: min(S.nlights, kLdsLights)
     uint32_t nm;         // materials cached: min(S.nmats, kLdsMats)
+    int *stack;          // this lane's column of a [kStack][kBlock] LDS array, free while a vertex is shaded
 };
 struct LightCacheStorage {
     float4 recs[4 * kLdsLights];
@@ -441,14 +447,14 @@ struct LightCacheStorage {
 };
 
 // Call from all threads of the workgroup; ends with a barrier.
-__device__ __forceinline__ LightCache load_light_cache(const DevScene &S, LightCacheStorage &st) {
+__device__ __forceinline__ LightCache load_light_cache(const DevScene &S, LightCacheStorage &st, int *lane_stack) {
     const uint32_t n = S.nlights < kLdsLights ? S.nlights : kLdsLights;
     const uint32_t nm = S.nmats < kLdsMats ? S.nmats : kLdsMats;
     for (uint32_t e = threadIdx.x; e < 4u * n; e += kBlock) st.recs[e] = S.tris[4 * (size_t)S.lights[e >> 2] + (e & 3u)];
     for (uint32_t e = threadIdx.x; e < 2u * nm; e += kBlock) st.mats[e] = reinterpret_cast<const float4 *>(S.mats)[e];
     for (uint32_t k = threadIdx.x; k < n; k += kBlock) st.ids[k] = (int)S.lights[k];
     __syncthreads();
-    return LightCache{st.recs, st.ids, st.mats, n, nm};
+    return LightCache{st.recs, st.ids, st.mats, n, nm, lane_stack};
 }
 
 __device__ __forceinline__ DevMaterial material(const DevScene &S, const LightCache &LC, uint32_t m) {
@@ -468,9 +474,93 @@ __device__ __forceinline__ float light_term(float4 q2, float4 q3, v3 x, v3 w, fl
 // LightSurface::pdf (main.cpp:771-783): sum over all lights except the surface's own triangle
 // of Triangle::pdf, in light-list order, no occlusion test, divided by the light count.  A light
 // the ray misses adds nothing (the reference skips it; here its term is never added either).
+// The same sum through the tree over the light triangles.  Every triangle the ray hits counts, so the
+// walk prunes nothing: it visits every node whose box the ray crosses, in "while-while" form (walk
+// inner nodes until the lane holds a leaf, then test that leaf's triangles together with the other
+// lanes).  The stack (this lane's LDS column) holds inner-node and leaf references alike and is
+// bounded by the tree height, like the main traversal's.
+// The reference adds the terms in light-list order and float addition does not associate, so one walk
+// keeps the (up to four) hits with the smallest light indices above `kmin`, sorted; their terms are
+// added in that order, and if the walk saw more hits it is repeated with kmin = the last index
+// added.  Nearly every direction hits at most two lights (in and out of one emissive solid).
+__device__ __forceinline__ float light_pdf_tree(const DevScene &S, int *stack, v3 x, v3 w, int self, uint32_t &tests) {
+    typedef Traversal<false>::f2 f2;
+    Traversal<false> T;
+    T.setup(S.lgrid_origin, S.lgrid_cell, x, w);
+    float ps = 0.f;
+    int kmin = -1;
+    bool more = T.cur != kSentinel;
+    while (more) {
+        more = false;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+        int k0 = kSentinel, k1 = kSentinel, k2 = kSentinel, k3 = kSentinel;
+        int sp = 0, cur = 0;
+        for (;;) {
+            while (cur >= 0 && cur != kSentinel) {
+                const uint4 n0 = S.lnodes[2 * (size_t)cur], n1 = S.lnodes[2 * (size_t)cur + 1];
+                const f2 lx = T.slab(n0.x, T.rx, T.ga.x, T.gn.x, T.gf.x), ly = T.slab(n0.y, T.ry, T.ga.y, T.gn.y, T.gf.y),
+                         lz = T.slab(n0.z, T.rz, T.ga.z, T.gn.z, T.gf.z);
+                const f2 qx = T.slab(n0.w, T.rx, T.ga.x, T.gn.x, T.gf.x), qy = T.slab(n1.x, T.ry, T.ga.y, T.gn.y, T.gf.y),
+                         qz = T.slab(n1.y, T.rz, T.ga.z, T.gn.z, T.gf.z);
+                const bool hL = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(lx.x, ly.x), lz.x), 0.f) <=
+                                __builtin_fminf(__builtin_fminf(lx.y, ly.y), lz.y);
+                const bool hR = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(qx.x, qy.x), qz.x), 0.f) <=
+                                __builtin_fminf(__builtin_fminf(qx.y, qy.y), qz.y);
+                const int cl = (int)n1.z, cr = (int)n1.w;
+                if (hL && hR) {
+                    stack[sp++ * kBlock] = cr;
+                    cur = cl;
+                } else if (hL) {
+                    cur = cl;
+                } else if (hR) {
+                    cur = cr;
+                } else {
+                    cur = sp ? stack[--sp * kBlock] : kSentinel;
+                }
+            }
+            if (cur == kSentinel) break;
+            const uint32_t ref = ~(uint32_t)cur;
+            const uint32_t first = ref >> 3, n = (ref & 7u) + 1u;
+            for (uint32_t j = 0; j < n; ++j) {
+                const float4 *tp = S.lrecs + 4 * (size_t)(first + j);
+                const float4 q3 = tp[3];
+                const int k = __float_as_int(q3.x);
+                if (__float_as_int(q3.y) == self || k <= kmin) continue;
+                ++tests;
+                float t;
+                if (!tri_test(tp[0], tp[1], tp[2], x, w, t)) continue;
+                if (k >= k3) {  // the four kept are all smaller: leave it to a later walk
+                    more = true;
+                    continue;
+                }
+                if (k3 != kSentinel) more = true;  // the largest kept one drops out
+                k3 = k, t3 = light_term(tp[2], q3, x, w, t);
+#define RT_ORDER(ka, ta, kb, tb)            \
+    if (kb < ka) {                          \
+        const int ki = ka;                  \
+        const float ti = ta;                \
+        ka = kb, ta = tb, kb = ki, tb = ti; \
+    }
+                RT_ORDER(k2, t2, k3, t3) RT_ORDER(k1, t1, k2, t2) RT_ORDER(k0, t0, k1, t1)
+#undef RT_ORDER
+            }
+            cur = sp ? stack[--sp * kBlock] : kSentinel;
+        }
+        ps = (((ps + t0) + t1) + t2) + t3;  // empty slots hold 0 and sort last: adding them changes nothing
+        kmin = k3;
+    }
+    return ps;
+}
+
+template <bool TREE>
 __device__ __forceinline__ float light_pdf(const DevScene &S, const LightCache &LC, v3 x, v3 w, int self,
                                            uint32_t &tests) {
     float ps = 0.f;
+    if (TREE) {
+        ps = light_pdf_tree(S, LC.stack, x, w, self, tests);
+        if (ps < kEps || __builtin_isnan(ps) || __builtin_isinf(ps)) return 0.f;
+        return ps / (float)S.nlights;
+    }
     for (uint32_t k = 0; k < LC.n; ++k) {
         if (LC.ids[k] == self) continue;
         ++tests;
@@ -492,6 +582,7 @@ __device__ __forceinline__ float light_pdf(const DevScene &S, const LightCache &
 
 // Processes the hit (t, tri) of ray (P.o, P.d): fills V, and when it returns true the path
 // continues with the new ray in P.o / P.d at depth P.depth - 1.  Touches P.o, P.d, P.rng, P.depth only.
+template <bool TREE>
 __device__ __forceinline__ bool sample_vertex(const DevScene &S, const LightCache &LC, PathState &P, float t, int tri,
                                               Vertex &V, uint32_t &lightTests) {
     V.op = kOpNone;
@@ -547,7 +638,7 @@ __device__ __forceinline__ bool sample_vertex(const DevScene &S, const LightCach
         }
         const float dn = dot(w, n);  // Cosine::pdf, main.cpp:748-754
         const float pc = (dn < kEps) ? 0.f : dn * kOneOverPi;
-        const float pdf = 0.5f * pc + 0.5f * light_pdf(S, LC, pPlus, w, tri, lightTests);
+        const float pdf = 0.5f * pc + 0.5f * light_pdf<TREE>(S, LC, pPlus, w, tri, lightTests);
         const float wn = dot(w, n);
         if (wn < 0.f || pdf < kEps) return false;  // V.op stays kOpEmit, main.cpp:1134-1136
         V.op = kOpDiffuse;
@@ -605,10 +696,11 @@ __device__ __forceinline__ void fold_forward(const DevScene &S, const LightCache
 }
 
 // Shades the hit (t, tri) of ray (P.o, P.d) in forward form.  Returns true when the path continues.
+template <bool TREE>
 __device__ __forceinline__ bool shade_hit(const DevScene &S, const LightCache &LC, PathState &P, float t, int tri,
                                           uint32_t &lightTests) {
     Vertex V;
-    const bool alive = sample_vertex(S, LC, P, t, tri, V, lightTests);
+    const bool alive = sample_vertex<TREE>(S, LC, P, t, tri, V, lightTests);
     fold_forward(S, LC, P, V);
     return alive;
 }

@@ -44,12 +44,29 @@ constexpr uint32_t kMaxTriangles = 1u << 28;
 // with AB = B-A, AC = C-A, N = cross(AB, AC) (unnormalised; its three components are exactly
 // the third-row cofactors of the reference's 3x3 inverse, main.cpp:481) and
 // pdfConst = 2 / |N| (main.cpp:532).
+struct FlatTree {
+    std::vector<uint32_t> nodes;   // nnodes * 8
+    std::vector<uint32_t> order;   // leaf position -> index of the triangle in the builder's input
+    float grid_origin[3] = {0.f, 0.f, 0.f};
+    float grid_cell[3] = {1.f, 1.f, 1.f};
+    uint32_t nnodes = 0;
+    uint32_t height = 0;
+};
+
 struct FlatScene {
     std::vector<uint32_t> nodes;    // nnodes * 8
     float grid_origin[3] = {0.f, 0.f, 0.f};
     float grid_cell[3] = {1.f, 1.f, 1.f};
     std::vector<float> tris;        // ntri * 16
     std::vector<uint32_t> lights;   // leaf-order positions of emissive triangles, loader order
+    // tree over the light triangles only (same node format, its own grid) and their records in that
+    // tree's leaf order: a triangle record whose word 12 = index in `lights`, word 13 = lights[index]
+    std::vector<uint32_t> light_nodes;
+    std::vector<float> light_recs;
+    float light_grid_origin[3] = {0.f, 0.f, 0.f};
+    float light_grid_cell[3] = {1.f, 1.f, 1.f};
+    uint32_t light_nnodes = 0;
+    uint32_t light_height = 0;
     uint32_t nnodes = 0;
     uint32_t ntri = 0;
     uint32_t tree_height = 0;

@@ -99,11 +99,11 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, uint32_t W, uint
 // One lane owns one pixel and runs its samples back to back; when a path ends the lane starts
 // the next sample in the same loop iteration ("path regeneration"), so lanes of a wave stay
 // busy although their paths have different lengths.
-template <bool COUNT>
+template <bool COUNT, bool TREE>
 __global__ __launch_bounds__(kBlock) void k_render_mega(DevScene S, rt::RenderParams rp, float *__restrict__ sum) {
     __shared__ int s_stack[kStack * kBlock];
     __shared__ LightCacheStorage s_lights;
-    const LightCache LC = load_light_cache(S, s_lights);
+    const LightCache LC = load_light_cache(S, s_lights, s_stack + threadIdx.x);
     uint32_t px, py;
     if (!tile_pixel(rp.W, rp.H, px, py)) return;
     const uint32_t pix = py * rp.W + px;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void k_render_mega(DevScene S, rt::RenderPa
         int tri;
         closest_hit<COUNT>(S, P.o, P.d, s_stack + threadIdx.x, t, tri, st);
         ++segs;
-        active = shade_hit(S, LC, P, t, tri, lightTests);
+        active = shade_hit<TREE>(S, LC, P, t, tri, lightTests);
         if (!active) acc = acc + P.L;  // color += generateSample(...), main.cpp:1224
     }
     sum[3 * (size_t)pix] = acc.x;
@@ -152,12 +152,12 @@ __global__ __launch_bounds__(kBlock) void k_render_mega(DevScene S, rt::RenderPa
 // libstdc++ / glibc sampling code this reproduces the CPU path's radiance sums bit for bit; it is
 // the validation kernel, not the fast one.  rec: [depth][3][stride] words (op | material << 3,
 // wn, pdf), stride = threads of the launch.
-template <bool COUNT>
+template <bool COUNT, bool TREE>
 __global__ __launch_bounds__(kBlock) void k_render_replay(DevScene S, rt::RenderParams rp, float *__restrict__ sum,
                                                           uint32_t *__restrict__ rec, uint32_t stride) {
     __shared__ int s_stack[kStack * kBlock];
     __shared__ LightCacheStorage s_lights;
-    const LightCache LC = load_light_cache(S, s_lights);
+    const LightCache LC = load_light_cache(S, s_lights, s_stack + threadIdx.x);
     uint32_t px, py;
     if (!tile_pixel(rp.W, rp.H, px, py)) return;
     const uint32_t pix = py * rp.W + px;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void k_render_replay(DevScene S, rt::Render
             closest_hit<COUNT>(S, P.o, P.d, s_stack + threadIdx.x, t, tri, st);
             ++segs;
             Vertex V;
-            const bool alive = sample_vertex(S, LC, P, t, tri, V, lightTests);
+            const bool alive = sample_vertex<TREE>(S, LC, P, t, tri, V, lightTests);
             uint32_t *r = rec + (size_t)nrec * 3u * stride + g;
             r[0] = (uint32_t)V.op | (V.mat << 3);
             r[stride] = __float_as_uint(V.wn);
@@ -312,6 +312,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
 // queue with ONE atomic and copies the buffer out with coalesced stores.
 constexpr uint32_t kAppendBuf = 2048;  // LDS entries per workgroup (8 KB); flushed above kAppendBuf - kBlock
 
+template <bool TREE>
 __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const uint32_t *__restrict__ queue,
                                                     const uint32_t *__restrict__ qcount_in,
                                                     uint32_t *__restrict__ queue_out, uint32_t *__restrict__ qcount_out,
@@ -319,7 +320,8 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const u
     __shared__ uint32_t s_buf[kAppendBuf];
     __shared__ uint32_t s_count, s_base;
     __shared__ LightCacheStorage s_lights;
-    const LightCache LC = load_light_cache(S, s_lights);
+    __shared__ int s_stack[TREE ? kStack * kBlock : 1];  // light_pdf's walk of the light tree
+    const LightCache LC = load_light_cache(S, s_lights, s_stack + (TREE ? threadIdx.x : 0));
     const uint32_t count = *qcount_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) *cursor = 0u;  // work cursor of the next extend pass
     if (threadIdx.x == 0) s_count = 0u;
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const u
             P.L = mk(s1.x, s1.y, s1.z);
             P.rng = __float_as_uint(s0.w);
             P.depth = __float_as_uint(s1.w);
-            alive = shade_hit(S, LC, P, r1.z, __float_as_int(r1.w), lightTests);
+            alive = shade_hit<TREE>(S, LC, P, r1.z, __float_as_int(r1.w), lightTests);
             V.state[2 * (size_t)i + 1] = make_float4(P.L.x, P.L.y, P.L.z, __uint_as_float(P.depth));
             if (alive) {
                 V.ray[2 * (size_t)i] = make_float4(P.o.x, P.o.y, P.o.z, P.d.x);
@@ -434,8 +436,9 @@ hipError_t launch_render_mega(const DevScene &S, const RenderParams &rp, float *
                               hipStream_t stream, KernelTimer &timer) {
     const uint32_t grid = pixel_grid(rp.W, rp.H);
     timer.begin(kKernMega, stream);
-    if (count) hipLaunchKernelGGL(k_render_mega<true>, dim3(grid), dim3(kBlock), 0, stream, S, rp, radiance_sum);
-    else hipLaunchKernelGGL(k_render_mega<false>, dim3(grid), dim3(kBlock), 0, stream, S, rp, radiance_sum);
+    auto kern = S.light_tree ? (count ? k_render_mega<true, true> : k_render_mega<false, true>)
+                             : (count ? k_render_mega<true, false> : k_render_mega<false, false>);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, stream, S, rp, radiance_sum);
     timer.end(stream);
     return hipGetLastError();
 }
@@ -449,8 +452,9 @@ hipError_t launch_render_replay(const DevScene &S, const RenderParams &rp, float
                                 hipStream_t stream, KernelTimer &timer) {
     const uint32_t grid = pixel_grid(rp.W, rp.H);
     timer.begin(kKernMega, stream);
-    if (count) hipLaunchKernelGGL(k_render_replay<true>, dim3(grid), dim3(kBlock), 0, stream, S, rp, radiance_sum, rec, grid * kBlock);
-    else hipLaunchKernelGGL(k_render_replay<false>, dim3(grid), dim3(kBlock), 0, stream, S, rp, radiance_sum, rec, grid * kBlock);
+    auto kern = S.light_tree ? (count ? k_render_replay<true, true> : k_render_replay<false, true>)
+                             : (count ? k_render_replay<true, false> : k_render_replay<false, false>);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, stream, S, rp, radiance_sum, rec, grid * kBlock);
     timer.end(stream);
     return hipGetLastError();
 }
@@ -486,7 +490,7 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
                                    wb.qcount + out, wb.qcount + 2);
             timer.end(stream);
             timer.begin(kKernShade, stream);
-            hipLaunchKernelGGL(wf_shade, dim3(grid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in, wb.queue[out],
+            hipLaunchKernelGGL(S.light_tree ? wf_shade<true> : wf_shade<false>, dim3(grid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in, wb.queue[out],
                                wb.qcount + out, wb.qcount + 2);
             timer.end(stream);
         }

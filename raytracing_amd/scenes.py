@@ -346,7 +346,40 @@ def glass_scene(path, grid=4, subdiv=4):
     return g.write(path)
 
 
+def emissive_mesh_scene(path, subdiv=3, lamps=3):
+    """Many light triangles: a closed diffuse room lit only by `lamps` emissive icospheres
+    (20*4^subdiv triangles each, so 3840 lights by default) with a mirror ball and a glass ball
+    between them.  Every light-pdf evaluation of the reference loops over all those triangles."""
+    g = GltfBuilder()
+    white = g.material(DIFFUSER, (0.75, 0.75, 0.75))
+    red = g.material(DIFFUSER, (0.7, 0.25, 0.2))
+    glow = [g.material(DIFFUSER, (0.8, 0.8, 0.8), emission=e, strength=6.0)
+            for e in ((1.0, 0.85, 0.6), (0.6, 0.8, 1.0), (0.9, 1.0, 0.8))]
+    mirror = g.material(METALLIC, (0.92, 0.92, 0.92))
+    glass = g.material(DIELECTRIC, (0.97, 0.99, 1.0))
+    room = g.mesh([
+        quad((-2, -1, 2), (2, -1, 2), (2, -1, -2), (-2, -1, -2)) + (white,),
+        quad((-2, 2, -2), (2, 2, -2), (2, 2, 2), (-2, 2, 2)) + (white,),
+        quad((-2, -1, -2), (2, -1, -2), (2, 2, -2), (-2, 2, -2)) + (red,),
+        quad((-2, -1, 2), (-2, -1, -2), (-2, 2, -2), (-2, 2, 2)) + (white,),
+        quad((2, -1, -2), (2, -1, 2), (2, 2, 2), (2, 2, -2)) + (white,),
+    ])
+    g.node(mesh=room)
+    sv, si = icosphere(subdiv)
+    for k in range(lamps):
+        a = 2.0 * np.pi * k / max(lamps, 1)
+        g.node(mesh=g.mesh([(sv, si, glow[k % len(glow)])]), translation=(1.1 * np.cos(a), 0.9 + 0.3 * (k % 2), 1.1 * np.sin(a) - 0.3),
+               scale=(0.28, 0.28, 0.28))
+    sv2, si2 = icosphere(max(subdiv - 1, 0))
+    g.node(mesh=g.mesh([(sv2, si2, mirror)]), translation=(-0.6, -0.6, 0.2), scale=(0.4, 0.4, 0.4))
+    g.node(mesh=g.mesh([(sv2, si2, glass)]), translation=(0.7, -0.65, 0.5), scale=(0.35, 0.35, 0.35))
+    cam = g.camera(0.75)
+    g.node(camera=cam, translation=(0.0, 0.4, 4.4), rotation=_quat_axis_angle((1, 0, 0), -0.1))
+    return g.write(path)
+
+
 SCENES = {
+    "emissive": emissive_mesh_scene,
     "cornell": cornell_box,
     "heightfield100k": heightfield_scene,
     "spheres1m": sphere_field_scene,

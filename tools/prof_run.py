@@ -31,7 +31,7 @@ def main():
     from raytracing_amd import scenes
 
     gens = {"spheres1m": ("spheres1m", {}), "cornell": ("cornell", {}), "hf100k": ("heightfield100k", {}),
-            "glass": ("glass", {"grid": 6, "subdiv": 5})}
+            "glass": ("glass", {"grid": 6, "subdiv": 5}), "emissive": ("emissive", {"subdiv": 4, "lamps": 3})}
     gen, kw = gens[a.workload]
     tmp = tempfile.mkdtemp(prefix="rt_prof_")
     path = scenes.generate(gen, os.path.join(tmp, gen + ".gltf"), **kw)
