@@ -61,6 +61,7 @@ SIGNATURES = {
     "rt_scene_get_stats": (C.c_int, [C.c_void_p, C.POINTER(SceneStats)]),
     "rt_scene_get_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_flat_build": (C.c_int, [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]),
+    "rt_flat_get_light_tree": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_flat_get": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_flat_free": (None, [C.c_void_p]),
     "rt_intersect_rays": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

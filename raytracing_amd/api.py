@@ -93,7 +93,7 @@ def node_boxes(nodes, grid):
 
 def build_flat(host_scene):
     """Host-only acceleration-structure build (no GPU): returns dict(nodes (n,8) u32, grid (6,) f32,
-    tris (m,16) f32, lights (k,) u32 leaf-order positions, height)."""
+    tris (m,16) f32, lights (k,) u32 leaf-order positions, height, light_tree=dict(nodes, grid, recs (k,16), height))."""
     if isinstance(host_scene, dict):
         host_scene = HostScene(**host_scene)
     L = _lib.lib()
@@ -108,9 +108,16 @@ def build_flat(host_scene):
         tris = np.empty((int(info[1]), 16), dtype=np.float32)
         lights = np.empty(int(info[2]), dtype=np.uint32)
         check(L.rt_flat_get(h, None, _p(grid), _p(nodes), _p(tris), _p(lights) if lights.size else None))
+        linfo = np.zeros(2, dtype=np.uint32)
+        check(L.rt_flat_get_light_tree(h, _p(linfo), None, None, None))
+        lgrid = np.empty(6, dtype=np.float32)
+        lnodes = np.empty((int(linfo[0]), 8), dtype=np.uint32)
+        lrecs = np.empty((lights.size, 16), dtype=np.float32)
+        check(L.rt_flat_get_light_tree(h, None, _p(lgrid), _p(lnodes), _p(lrecs) if lights.size else None))
     finally:
         L.rt_flat_free(h)
-    return dict(nodes=nodes, grid=grid, tris=tris, lights=lights, height=int(info[3]))
+    return dict(nodes=nodes, grid=grid, tris=tris, lights=lights, height=int(info[3]),
+                light_tree=dict(nodes=lnodes, grid=lgrid, recs=lrecs, height=int(linfo[1])))
 
 
 class Scene:

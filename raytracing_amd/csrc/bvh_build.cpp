@@ -481,6 +481,26 @@ int rt_flat_get(const rt_flat *f, uint32_t info[4], float grid[6], uint32_t *nod
     return RT_OK;
 }
 
+int rt_flat_get_light_tree(const rt_flat *f, uint32_t info[2], float grid[6], uint32_t *nodes, float *recs) {
+    if (!f) {
+        rt::set_error("rt_flat_get_light_tree: null argument");
+        return RT_ERR_INVALID;
+    }
+    const rt::FlatScene &s = f->flat;
+    if (info) {
+        info[0] = s.light_nnodes;
+        info[1] = s.light_height;
+    }
+    if (grid)
+        for (int a = 0; a < 3; ++a) {
+            grid[a] = s.light_grid_origin[a];
+            grid[3 + a] = s.light_grid_cell[a];
+        }
+    if (nodes) std::memcpy(nodes, s.light_nodes.data(), (size_t)s.light_nnodes * 8 * sizeof(uint32_t));
+    if (recs) std::memcpy(recs, s.light_recs.data(), s.lights.size() * 16 * sizeof(float));
+    return RT_OK;
+}
+
 void rt_flat_free(rt_flat *f) { delete f; }
 
 }  // extern "C"

@@ -164,8 +164,40 @@ def _check_flat(flat, tri_verts, tri_material, materials):
     em = np.linalg.norm(materials["emission"][tri_material], axis=1) > 1e-4
     assert np.array_equal(ids[flat["lights"]], np.flatnonzero(em))     # loader order, leaf positions
 
+    # the tree over the light triangles: every light in exactly one leaf, inside its box, records = the triangles'
+    lt = flat["light_tree"]
+    lights = flat["lights"]
+    nl = lights.size
+    recs = lt["recs"]
+    assert sorted(recs[:, 12].view(np.uint32).tolist()) == list(range(nl))
+    assert np.array_equal(recs[:, 13].view(np.uint32), lights[recs[:, 12].view(np.uint32)])
+    assert np.array_equal(recs[:, :12], tris[recs[:, 13].view(np.uint32), :12]) and np.array_equal(recs[:, 14], tris[recs[:, 13].view(np.uint32), 14])
+    lrefs = lt["nodes"][:, 6:8].view(np.int32)
+    lboxes = rt.api.node_boxes(lt["nodes"], lt["grid"])
+    labsent = (lt["nodes"][:, :6].reshape(-1, 2, 3) == 0xFFFFFFFF).all(axis=2)
+    lseen = np.zeros(max(nl, 1), dtype=np.int32)
 
-@pytest.mark.parametrize("name,kw", [("cornell", {}), ("heightfield100k", {"nx": 40, "nz": 40}),
+    def lwalk(node, level):
+        h = level
+        for side in range(2):
+            ref, b = lrefs[node, side], lboxes[node, side]
+            if labsent[node, side]:
+                continue
+            if ref < 0:
+                r = ~int(ref)
+                for k in range(r >> 3, (r >> 3) + (r & 7) + 1):
+                    lseen[k] += 1
+                    tid = ids[int(recs[k, 13].view(np.uint32))]
+                    assert (tmin[tid] >= b[:3]).all() and (tmax[tid] <= b[3:]).all()
+            else:
+                h = max(h, lwalk(int(ref), level + 1))
+        return h
+
+    if nl:
+        assert lwalk(0, 1) == lt["height"] <= 24 and (lseen[:nl] == 1).all()
+
+
+@pytest.mark.parametrize("name,kw", [("cornell", {}), ("emissive", {"subdiv": 2, "lamps": 2}), ("heightfield100k", {"nx": 40, "nz": 40}),
                                      ("spheres1m", {"n_spheres": 10, "subdiv": 2, "ground": 8})])
 def test_flat_bvh_is_valid(scene_dir, name, kw):
     import sys
