@@ -183,7 +183,7 @@ def main():
 
     # ---- primary-ray closest hit on the 100k-triangle mesh (informational) ----------------------
     extra = {}
-    if not args.no_primary:
+    if not args.no_primary and world == 1:
         p2 = scenes.generate("heightfield100k", os.path.join(tmp, "hf100k.gltf"))
         s2 = rt.Scene(rt.load_gltf(p2, 1920, 1080), device=local_rank)
         ids = torch.empty(1920 * 1080, dtype=torch.int32, device=dev)
@@ -204,7 +204,7 @@ def main():
 
     # ---- CPU baseline: the oracle (a port of the reference's CPU path) on this host's cores ------
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # reported once, by the single-GPU run
         from oracle import oracle
         cw, ch, cspp = W // 4, H // 4, 4
         host_small = rt.load_gltf(path, cw, ch).as_dict()
