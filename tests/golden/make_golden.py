@@ -11,6 +11,8 @@ absent), so nothing here was produced BY the reference:
   cornell_64x48.npz  oracle outputs for the generated Cornell scene: primary-hit ids / distances and
                      4-spp radiance sums in both RNG modes.  They pin the ORACLE against regressions
                      and give the GPU tests a committed target; they do not pin it to the reference.
+  emissive_48x36.npz the same for the emissive-mesh scene at 160 light triangles (light-pdf sums over many
+                     lights; the GPU evaluates them through its light tree).
 """
 import json
 import os
@@ -62,7 +64,19 @@ def main():
     np.savez_compressed(os.path.join(HERE, "cornell_64x48.npz"), ids=ids, t=t, tie=tie, sum_reference_rng=ref,
                         sum_counter_rng=ctr, segments=np.array([cnt0["segments"], cnt1["segments"]], dtype=np.uint64),
                         tri_verts=sc["tri_verts"])
-    print("wrote rng_kat.json and cornell_64x48.npz")
+
+    W, H, spp = 48, 36, 2
+    with tempfile.TemporaryDirectory() as d:
+        sc = gltf_ref.parse_gltf(scenes.emissive_mesh_scene(os.path.join(d, "emissive.gltf"), subdiv=1, lamps=2), W, H)
+    orc = oracle.OracleScene(sc["tri_verts"], sc["tri_material"], sc["materials"], sc["camera"])
+    ids, t, tie, _ = orc.trace_primary(W, H)
+    ref, cnt0 = orc.render(W, H, spp, max_depth=5, rng_mode=0)
+    ctr, cnt1 = orc.render(W, H, spp, max_depth=5, rng_mode=1, seed=11)
+    np.savez_compressed(os.path.join(HERE, "emissive_48x36.npz"), ids=ids, t=t, tie=tie, sum_reference_rng=ref,
+                        sum_counter_rng=ctr, segments=np.array([cnt0["segments"], cnt1["segments"]], dtype=np.uint64),
+                        light_tests=np.array([cnt0["light_tests"], cnt1["light_tests"]], dtype=np.uint64),
+                        tri_verts=sc["tri_verts"])
+    print("wrote rng_kat.json, cornell_64x48.npz and emissive_48x36.npz")
 
 
 if __name__ == "__main__":

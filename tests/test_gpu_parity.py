@@ -185,6 +185,19 @@ def test_golden_cornell_fixture(scene_dir, oracle_mod):
                       g["sum_counter_rng"])
 
 
+def test_golden_emissive_fixture(scene_dir, oracle_mod):
+    """tests/golden/emissive_48x36.npz: 160 light triangles, so the light pdf goes through the light tree."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "emissive_48x36.npz"))
+    host, gpu, orc = _load(scene_dir, oracle_mod, "emissive", 48, 36, subdiv=1, lamps=2)
+    assert np.array_equal(host.tri_verts, g["tri_verts"]) and gpu.stats()["nlights"] == 160
+    ids, t = gpu.trace_primary(48, 36)
+    _compare_hits(ids, t, g["ids"], g["t"], g["tie"])
+    _assert_bits_equal(gpu.render(48, 36, 2, rng_mode=0, max_depth=5), g["sum_reference_rng"])
+    for pipe in (0, 1):
+        _assert_close(gpu.render(48, 36, 2, rng_mode=1, max_depth=5, seed=11, pipeline=pipe), g["sum_counter_rng"])
+
+
 def test_config2_full_size_primary_hits(scene_dir, oracle_mod):
     """BASELINE config 2 at full size: 100 354-triangle mesh, 1920x1080 primary rays, hit ids and
     distances bit for bit against the oracle (which builds its own, different, BVH)."""

@@ -55,6 +55,20 @@ def test_golden_cornell(oracle_mod, scene_dir):
     assert [c0["segments"], c1["segments"]] == [int(x) for x in g["segments"]]
 
 
+def test_golden_emissive(oracle_mod, scene_dir):
+    g = np.load(os.path.join(GOLDEN, "emissive_48x36.npz"))
+    sc, orc = _oracle_scene(oracle_mod, make_scene(scene_dir, "emissive", subdiv=1, lamps=2), 48, 36)
+    assert np.array_equal(sc["tri_verts"], g["tri_verts"]) and orc.info()["lights"] == 160
+    ids, t, tie, _ = orc.trace_primary(48, 36)
+    assert np.array_equal(ids, g["ids"]) and np.array_equal(t.view(np.uint32), g["t"].view(np.uint32))
+    ref, c0 = orc.render(48, 36, 2, max_depth=5, rng_mode=0)
+    ctr, c1 = orc.render(48, 36, 2, max_depth=5, rng_mode=1, seed=11)
+    assert np.array_equal(ref.view(np.uint32), g["sum_reference_rng"].view(np.uint32))
+    assert np.array_equal(ctr.view(np.uint32), g["sum_counter_rng"].view(np.uint32))
+    assert [c0["segments"], c1["segments"]] == [int(x) for x in g["segments"]]
+    assert [c0["light_tests"], c1["light_tests"]] == [int(x) for x in g["light_tests"]]
+
+
 @pytest.mark.parametrize("name,kw", [("cornell", {}), ("heightfield100k", {"nx": 24, "nz": 24}),
                                      ("glass", {"grid": 2, "subdiv": 1}),
                                      ("spheres1m", {"n_spheres": 12, "subdiv": 1, "ground": 8})])
