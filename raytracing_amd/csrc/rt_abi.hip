@@ -84,6 +84,7 @@ void free_wavefront(rt_scene *s) {
     (void)hipFree(w.queue[0]);
     (void)hipFree(w.queue[1]);
     (void)hipFree(w.qcount);
+    (void)hipFree(w.cursors);
     w = rt::WavefrontBuffers();
 }
 
@@ -109,6 +110,8 @@ int ensure_wavefront(rt_scene *s, uint32_t npix) {
     RT_HIP(dev_alloc(s, &w.queue[1], (size_t)cap));
     RT_HIP(dev_alloc(s, &w.qcount, (size_t)4));
     RT_HIP(hipMemset(w.qcount, 0, 4 * sizeof(uint32_t)));
+    RT_HIP(dev_alloc(s, &w.cursors, rt::kWfCursorWords));
+    RT_HIP(hipMemset(w.cursors, 0, rt::kWfCursorWords * sizeof(uint32_t)));
     w.capacity = cap;
     return RT_OK;
 }

@@ -209,6 +209,10 @@ __global__ __launch_bounds__(kBlock) void k_render_replay(DevScene S, rt::Render
 // queues hold the slot indices still alive.  Slot i renders pixel i % npix, sample
 // spp0 + i / npix.
 // ---------------------------------------------------------------------------------------------
+constexpr uint32_t kShards = 8;           // work cursors of wf_extend (see there)
+constexpr uint32_t kCursorStride = 1024;  // words between cursors
+static_assert(kShards * kCursorStride == rt::kWfCursorWords, "cursor buffer size");
+
 struct WfView {
     float4 *ray;    // [2i] = (o.xyz, d.x)  [2i+1] = (d.y, d.z, hit t, bits(hit triangle))
     float4 *state;  // [2i] = (throughput.xyz, bits(rng))  [2i+1] = (radiance.xyz, bits(depth left))
@@ -216,7 +220,8 @@ struct WfView {
 };
 
 __global__ __launch_bounds__(kBlock) void wf_generate(DevScene S, rt::RenderParams rp, WfView V, uint32_t npaths,
-                                                       uint32_t spp0, uint32_t *__restrict__ qcount) {
+                                                       uint32_t spp0, uint32_t *__restrict__ qcount,
+                                                       uint32_t *__restrict__ cursors) {
     const uint32_t npix = rp.W * rp.H;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npaths; i += gridDim.x * kBlock) {
         const uint32_t pix = i % npix, sample = spp0 + i / npix;
@@ -231,23 +236,32 @@ __global__ __launch_bounds__(kBlock) void wf_generate(DevScene S, rt::RenderPara
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         qcount[0] = npaths;
         qcount[1] = 0u;
-        qcount[2] = 0u;  // work cursor of the first extend pass
     }
+    if (blockIdx.x == 0 && threadIdx.x < kShards) cursors[threadIdx.x * kCursorStride] = 0u;  // first extend pass
 }
 
 // Traces the rays of the input queue (null queue = identity: slots 0..count-1) and stores the hit.
 // Persistent waves with per-lane dynamic ray fetch: a lane whose ray has finished takes the next
 // ray of the queue instead of idling until the slowest lane of its wave is done.  A wave grabs
-// kChunk consecutive queue entries with one atomic on the work cursor and deals them to its idle
-// lanes (ballot + prefix count) whenever at least kRefill lanes are idle.  kChunk is large because
-// the cursor is one word of global memory (about 88 atomics per microsecond for the whole chip).
-constexpr uint32_t kChunk = 512;
+// kChunk consecutive queue entries with one atomic on a work cursor and deals them to its idle
+// lanes (ballot + prefix count) whenever at least kRefill lanes are idle.
+// One word of global memory takes only ~88 atomics per microsecond for the whole chip, and the chunk
+// size trades that against the end of the launch, where every wave still works through its last chunk
+// (512 rays = 8 per lane took 0.7 ms on the million-triangle scene: the waves' finishing times spread
+// over 17 % of a 33 M-ray launch).  So the queue is cut into kShards equal ranges with a cursor each,
+// 4 KB apart; a workgroup starts on shard blockIdx % kShards (with round-robin dispatch, its XCD's)
+// and moves on to the next shard when one runs dry.  Eight cursors take eight times the atomics, which
+// lets the chunk be 128 rays.
+#ifndef RT_CHUNK
+#define RT_CHUNK 128
+#endif
+constexpr uint32_t kChunk = RT_CHUNK;
 constexpr int kRefill = 12;  // insensitive: 4 / 12 / 24 / 32 idle lanes all within 1 %
 
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const uint32_t *__restrict__ queue,
                                                      const uint32_t *__restrict__ qcount_in,
-                                                     uint32_t *__restrict__ qcount_zero, uint32_t *__restrict__ cursor) {
+                                                     uint32_t *__restrict__ qcount_zero, uint32_t *__restrict__ cursors) {
     __shared__ int s_stack[kStack * kBlock];
     const uint32_t count = *qcount_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) *qcount_zero = 0u;  // the queue the next shade pass fills
@@ -258,7 +272,8 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
     uint32_t slot = 0, segs = 0;
     bool hasRay = false;
     uint32_t chunkNext = 0, chunkEnd = 0;  // wave-uniform
-    bool exhausted = false;                // wave-uniform: the cursor ran past the queue
+    uint32_t shard = blockIdx.x % kShards, dry = 0;  // wave-uniform: current shard, shards found empty in a row
+    bool exhausted = false;                // wave-uniform: every shard ran dry
     TraceStats st{0, 0, 0, 0};
     for (;;) {
         if (hasRay && T.done()) {
@@ -274,15 +289,23 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
             uint32_t given = 0;
             while (given < (uint32_t)nIdle) {
                 if (chunkNext == chunkEnd) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(cursor, kChunk);
-                    base = __shfl(base, 0);
-                    if (base >= count) {
-                        exhausted = true;
-                        break;
+                    // shard s covers [count * s / kShards, count * (s + 1) / kShards)
+                    const uint32_t lo = (uint32_t)((uint64_t)count * shard / kShards);
+                    const uint32_t hi = (uint32_t)((uint64_t)count * (shard + 1u) / kShards);
+                    uint32_t off = 0;
+                    if (lane == 0) off = atomicAdd(cursors + shard * kCursorStride, kChunk);
+                    off = __shfl(off, 0);
+                    if (off >= hi - lo) {
+                        shard = (shard + 1u) % kShards;
+                        if (++dry == kShards) {
+                            exhausted = true;
+                            break;
+                        }
+                        continue;
                     }
-                    chunkNext = base;
-                    chunkEnd = (count - base < kChunk) ? count : base + kChunk;
+                    dry = 0;
+                    chunkNext = lo + off;
+                    chunkEnd = (hi - chunkNext < kChunk) ? hi : chunkNext + kChunk;
                 }
                 const uint32_t avail = chunkEnd - chunkNext;
                 const uint32_t take = avail < (uint32_t)nIdle - given ? avail : (uint32_t)nIdle - given;
@@ -316,14 +339,14 @@ template <bool TREE>
 __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const uint32_t *__restrict__ queue,
                                                     const uint32_t *__restrict__ qcount_in,
                                                     uint32_t *__restrict__ queue_out, uint32_t *__restrict__ qcount_out,
-                                                    uint32_t *__restrict__ cursor) {
+                                                    uint32_t *__restrict__ cursors) {
     __shared__ uint32_t s_buf[kAppendBuf];
     __shared__ uint32_t s_count, s_base;
     __shared__ LightCacheStorage s_lights;
     __shared__ int s_stack[TREE ? kStack * kBlock : 1];  // light_pdf's walk of the light tree
     const LightCache LC = load_light_cache(S, s_lights, s_stack + (TREE ? threadIdx.x : 0));
     const uint32_t count = *qcount_in;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *cursor = 0u;  // work cursor of the next extend pass
+    if (blockIdx.x == 0 && threadIdx.x < kShards) cursors[threadIdx.x * kCursorStride] = 0u;  // next extend pass
     if (threadIdx.x == 0) s_count = 0u;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
@@ -475,7 +498,7 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
         const uint32_t egrid = grid < kExtendBlocks ? grid : kExtendBlocks;
         timer.begin(kKernGenerate, stream);
         hipLaunchKernelGGL(wf_generate, dim3(grid), dim3(kBlock), 0, stream, S, rp, V, npaths, rp.spp_begin + done,
-                           wb.qcount);
+                           wb.qcount, wb.cursors);
         timer.end(stream);
         const uint32_t bounces = rp.max_depth ? rp.max_depth : 1u;  // depth 0 still traces the camera ray
         for (uint32_t b = 0; b < bounces; ++b) {
@@ -484,14 +507,14 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
             timer.begin(kKernExtend, stream);
             if (count)
                 hipLaunchKernelGGL(wf_extend<true>, dim3(egrid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in,
-                                   wb.qcount + out, wb.qcount + 2);
+                                   wb.qcount + out, wb.cursors);
             else
                 hipLaunchKernelGGL(wf_extend<false>, dim3(egrid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in,
-                                   wb.qcount + out, wb.qcount + 2);
+                                   wb.qcount + out, wb.cursors);
             timer.end(stream);
             timer.begin(kKernShade, stream);
             hipLaunchKernelGGL(S.light_tree ? wf_shade<true> : wf_shade<false>, dim3(grid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in, wb.queue[out],
-                               wb.qcount + out, wb.qcount + 2);
+                               wb.qcount + out, wb.cursors);
             timer.end(stream);
         }
         const uint32_t agrid = (npix + kBlock - 1) / kBlock < kPersistentBlocks ? (npix + kBlock - 1) / kBlock

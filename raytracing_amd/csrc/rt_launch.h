@@ -83,12 +83,15 @@ struct RenderParams {
 // quarters so that a lane moves a record with four loads or stores: the vector-memory path charges
 // per lane and instruction, not per byte), two index queues, queue counters.  Owned by the scene,
 // sized on first use.
+constexpr size_t kWfCursorWords = 8 * 1024;  // 8 cursors, 4 KB apart (rt_kernels.hip: kShards x kCursorStride)
 struct WavefrontBuffers {
     uint32_t capacity = 0;
     float4 *ray = nullptr;    // 2 x capacity: [2i] = (o.xyz, d.x)  [2i+1] = (d.y, d.z, hit t, bits(hit triangle))
     float4 *state = nullptr;  // 2 x capacity: [2i] = (throughput.xyz, bits(rng))  [2i+1] = (radiance.xyz, bits(depth left))
     uint32_t *queue[2] = {nullptr, nullptr};  // path indices alive in the current / next bounce
-    uint32_t *qcount = nullptr; // [0], [1]: queue lengths (device), [2..]: spare
+    uint32_t *qcount = nullptr; // [0], [1]: queue lengths (device)
+    uint32_t *cursors = nullptr; // work cursors of the extend kernel, kWfCursorWords words
+
 };
 
 hipError_t launch_intersect(const rtd::DevScene &S, uint64_t n, const float *o, const float *d, uint32_t *prim_id,
