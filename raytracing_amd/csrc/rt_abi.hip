@@ -88,12 +88,14 @@ void free_wavefront(rt_scene *s) {
     w = rt::WavefrontBuffers();
 }
 
-// Path records in flight per wavefront pass: whole frames of samples, about 32M paths (2.4 GB of
-// records and queues).  The deeper bounces of a pass keep only a few percent of its paths alive, and
-// with 4M paths they left most of the chip idle: 4M -> 1588, 8M -> 1817, 16M -> 1988, 32M -> 2070,
-// 64M -> 2105 Mrays/s on the million-triangle 1080p depth-8 workload.  RT_WF_PATHS overrides.
+// Path records in flight per wavefront pass: whole frames of samples, up to 64 of them or about 128M
+// paths (72 B each with the queues: 9.7 GB of the 288 GB).  The deeper bounces of a pass keep only a
+// few percent of its paths alive, and every launch pays a ramp and a drain of about one ray's
+// duration, so fewer, larger launches win: 16M -> 3424, 32M -> 3656, 64M -> 3763, 128M -> 3827 Mrays/s
+// on the million-triangle 1080p depth-8 workload (4M: 1588 before the other optimisations).
+// RT_WF_PATHS overrides.
 int ensure_wavefront(rt_scene *s, uint32_t npix) {
-    uint64_t target = 32u << 20;
+    uint64_t target = 128u << 20;
     if (const char *e = std::getenv("RT_WF_PATHS")) target = std::strtoull(e, nullptr, 0);
     uint64_t slots = target / npix;
     if (slots < 1) slots = 1;
