@@ -158,8 +158,8 @@ int rt_flat_build(const rt_scene_desc *desc, rt_flat **out);
 int rt_flat_get(const rt_flat *f, uint32_t info[4], float grid[6], uint32_t *nodes, float *tris,
                 uint32_t *lights);
 /* The second tree of the same build, over the light triangles only; LightSurface::pdf
- * (main.cpp:771-783) walks it instead of looping over the light list when a scene has more than
- * 64 lights (environment RT_LIGHT_TREE_MIN overrides that count at rt_scene_create).
+ * (main.cpp:771-783) walks it instead of looping over the light list when a scene has 48
+ * lights or more (environment RT_LIGHT_TREE_MIN overrides that count at rt_scene_create).
  * info[0] = node count, [1] = tree height; grid and nodes as in rt_flat_get; recs: one triangle
  * record (16 floats) per light in this tree's leaf order, word 12 = index in the light list,
  * word 13 = the light's leaf position in the main triangle array.  Any pointer may be NULL. */
