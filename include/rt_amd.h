@@ -130,6 +130,21 @@ int rt_device_count(void);
 
 /* ---- scene files: stands in for parseGLTF, main.cpp:866-1111 (host only, no GPU call) ---- */
 int rt_gltf_load(const char *path, uint32_t width, uint32_t height, rt_host_scene **out);
+/* The same loader with opt-in departures from the reference's rules towards the glTF 2.0
+ * specification (each changes what some files mean, so none is on by default):
+ * STRIDE: bufferView.byteStride is honoured for POSITION and bufferView.byteOffset may be absent
+ * (reference: stride 12 always, byteOffset required, main.cpp:885-891, 1044-1050);
+ * INDEX_OFFSET: accessor.byteOffset applies to index accessors too (reference ignores it,
+ * main.cpp:1060-1078); DATA_URI: base64 `data:` buffers (reference: external files only, 875-882);
+ * HIERARCHY: a node's world transform is the product along its parent chain whatever the node
+ * order, and the camera uses its world transform (reference: one ascending pass, camera local
+ * only, main.cpp:1015-1026). */
+#define RT_GLTF_STRIDE 1u
+#define RT_GLTF_INDEX_OFFSET 2u
+#define RT_GLTF_DATA_URI 4u
+#define RT_GLTF_HIERARCHY 8u
+#define RT_GLTF_SPEC 15u
+int rt_gltf_load_ex(const char *path, uint32_t width, uint32_t height, uint32_t flags, rt_host_scene **out);
 int rt_host_scene_get_desc(const rt_host_scene *hs, rt_scene_desc *out); /* pointers stay owned by hs */
 void rt_host_scene_free(rt_host_scene *hs);
 

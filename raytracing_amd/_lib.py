@@ -54,6 +54,7 @@ SIGNATURES = {
     "rt_last_error": (C.c_char_p, []),
     "rt_device_count": (C.c_int, []),
     "rt_gltf_load": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "rt_gltf_load_ex": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "rt_host_scene_get_desc": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
     "rt_host_scene_free": (None, [C.c_void_p]),
     "rt_scene_create": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]),

@@ -57,11 +57,15 @@ class HostScene:
         return d
 
 
-def load_gltf(path, width, height):
-    """The host part of parseGLTF (main.cpp:866-1104): no GPU involved."""
+GLTF_STRIDE, GLTF_INDEX_OFFSET, GLTF_DATA_URI, GLTF_HIERARCHY, GLTF_SPEC = 1, 2, 4, 8, 15
+
+
+def load_gltf(path, width, height, flags=0):
+    """The host part of parseGLTF (main.cpp:866-1104): no GPU involved.  `flags` (GLTF_*) opt into
+    glTF 2.0 rules the reference does not follow; 0 = the reference's reading of the file."""
     L = _lib.lib()
     h = C.c_void_p()
-    check(L.rt_gltf_load(str(path).encode(), int(width), int(height), C.byref(h)))
+    check(L.rt_gltf_load_ex(str(path).encode(), int(width), int(height), int(flags), C.byref(h)))
     try:
         d = _lib.SceneDesc()
         check(L.rt_host_scene_get_desc(h, C.byref(d)))

@@ -13,6 +13,13 @@
 //   * every node with a mesh is instantiated, `scenes` is ignored (1028-1031)
 // Unlike the reference (undefined behaviour on a missing key, no bounds checks), malformed
 // input is rejected with an error message.
+// rt_gltf_load_ex adds opt-in flags that follow the glTF 2.0 specification where the reference
+// does not (they change what some files mean, so they are off by default):
+//   RT_GLTF_STRIDE      bufferView.byteStride for POSITION; bufferView.byteOffset defaults to 0
+//   RT_GLTF_INDEX_OFFSET  accessor.byteOffset also applies to index accessors
+//   RT_GLTF_DATA_URI    base64 `data:` buffers
+//   RT_GLTF_HIERARCHY   world transform = product along the parent chain whatever the node order;
+//                       the camera takes its world transform
 #include <chrono>
 #include <cstring>
 #include <fstream>
@@ -28,7 +35,7 @@ namespace {
 const float EPS = 0.0001f;  // main.cpp:22
 
 struct BufferView {
-    size_t buffer, byteLength, byteOffset;
+    size_t buffer, byteLength, byteOffset, byteStride;
 };
 struct Accessor {
     size_t bufferView, count, componentType, byteOffset;
@@ -71,7 +78,34 @@ size_t read_index(const std::vector<char> &b, size_t off, size_t width) {
     return v;
 }
 
-void load(const std::string &path, uint32_t width, uint32_t height, rt_host_scene &out) {
+std::vector<char> decode_base64(const std::string &text, size_t begin, size_t nbytes) {
+    std::vector<char> outv;
+    outv.reserve(nbytes);
+    uint32_t acc = 0;
+    int bits = 0;
+    for (size_t i = begin; i < text.size(); ++i) {
+        const char c = text[i];
+        int v;
+        if (c >= 'A' && c <= 'Z') v = c - 'A';
+        else if (c >= 'a' && c <= 'z') v = c - 'a' + 26;
+        else if (c >= '0' && c <= '9') v = c - '0' + 52;
+        else if (c == '+' || c == '-') v = 62;
+        else if (c == '/' || c == '_') v = 63;
+        else if (c == '=') break;
+        else throw std::runtime_error("data URI holds a character outside base64");
+        acc = (acc << 6) | (uint32_t)v;
+        bits += 6;
+        if (bits >= 8) {
+            bits -= 8;
+            outv.push_back((char)((acc >> bits) & 0xFFu));
+        }
+    }
+    if (outv.size() < nbytes) throw std::runtime_error("data URI shorter than byteLength");
+    outv.resize(nbytes);
+    return outv;
+}
+
+void load(const std::string &path, uint32_t width, uint32_t height, uint32_t flags, rt_host_scene &out) {
     using jsonmin::Value;
     std::ifstream in(path);
     if (!in) throw std::runtime_error("cannot open scene file " + path);
@@ -81,13 +115,23 @@ void load(const std::string &path, uint32_t width, uint32_t height, rt_host_scen
     const std::string base = dir_of(path);
 
     std::vector<std::vector<char>> buffers;  // main.cpp:874-882
-    for (const Value &b : data.at("buffers").a)
-        buffers.push_back(read_file(base + b.at("uri").as_string(), (size_t)b.at("byteLength").as_index()));
+    for (const Value &b : data.at("buffers").a) {
+        const std::string uri = b.at("uri").as_string();
+        const size_t nbytes = (size_t)b.at("byteLength").as_index();
+        if ((flags & RT_GLTF_DATA_URI) && uri.rfind("data:", 0) == 0) {
+            const size_t comma = uri.find(";base64,");
+            if (comma == std::string::npos) throw std::runtime_error("data URI is not base64");
+            buffers.push_back(decode_base64(uri, comma + 8, nbytes));
+        } else {
+            buffers.push_back(read_file(base + uri, nbytes));
+        }
+    }
 
     std::vector<BufferView> views;  // main.cpp:884-891
     for (const Value &v : data.at("bufferViews").a) {
-        BufferView bv{(size_t)v.at("buffer").as_index(), (size_t)v.at("byteLength").as_index(),
-                      (size_t)v.at("byteOffset").as_index()};
+        BufferView bv{(size_t)v.at("buffer").as_index(), (size_t)v.at("byteLength").as_index(), 0, 0};
+        if (!(flags & RT_GLTF_STRIDE) || v.contains("byteOffset")) bv.byteOffset = (size_t)v.at("byteOffset").as_index();
+        if ((flags & RT_GLTF_STRIDE) && v.contains("byteStride")) bv.byteStride = (size_t)v.at("byteStride").as_index();
         if (bv.buffer >= buffers.size()) throw std::runtime_error("bufferView names a missing buffer");
         views.push_back(bv);
     }
@@ -158,6 +202,7 @@ void load(const std::string &path, uint32_t width, uint32_t height, rt_host_scen
     hm::vec3 camRight = hm::V3(1.f, 0.f, 0.f), camUp = hm::V3(0.f, 1.f, 0.f), camFwd = hm::V3(0.f, 0.f, -1.f);
     hm::vec3 camPos = hm::V3(0.f, 0.f, 0.f);
     float tanY = 0.f;
+    size_t cameraNode = (size_t)-1;
 
     const std::vector<Value> &nodes = data.at("nodes").a;
     std::vector<hm::mat4> transitions;
@@ -213,6 +258,7 @@ void load(const std::string &path, uint32_t width, uint32_t height, rt_host_scen
             float yfov = data.at("cameras").idx((size_t)node.at("camera").as_index()).at("perspective")
                              .at("yfov").as_float();
             tanY = std::tan(yfov / 2.f);
+            cameraNode = transitions.size() - 1;
             camPos = translation;
             camRight = hm::rotate(rotation, camRight);
             camUp = hm::rotate(rotation, camUp);
@@ -220,8 +266,39 @@ void load(const std::string &path, uint32_t width, uint32_t height, rt_host_scen
         }
     }
 
-    for (size_t i = 0; i < transitions.size(); ++i)  // main.cpp:1022-1026
-        for (size_t child : children[i]) transitions[child] = transitions[i] * transitions[child];
+    if (flags & RT_GLTF_HIERARCHY) {
+        // world = parent's world * local, parents first whatever their indices
+        std::vector<size_t> parent(transitions.size(), (size_t)-1);
+        for (size_t i = 0; i < transitions.size(); ++i)
+            for (size_t child : children[i]) {
+                if (parent[child] != (size_t)-1) throw std::runtime_error("node has two parents");
+                parent[child] = i;
+            }
+        std::vector<size_t> order;
+        std::vector<size_t> stack;
+        for (size_t i = 0; i < transitions.size(); ++i)
+            if (parent[i] == (size_t)-1) stack.push_back(i);
+        while (!stack.empty()) {
+            const size_t i = stack.back();
+            stack.pop_back();
+            order.push_back(i);
+            for (size_t child : children[i]) stack.push_back(child);
+        }
+        if (order.size() != transitions.size()) throw std::runtime_error("node hierarchy has a cycle");
+        for (size_t i : order)
+            if (parent[i] != (size_t)-1) transitions[i] = transitions[parent[i]] * transitions[i];
+        if (cameraNode != (size_t)-1) {
+            const hm::mat4 &w = transitions[cameraNode];
+            const hm::quat q = hm::to_quat(w);
+            camPos = hm::V3(w.c[3].x, w.c[3].y, w.c[3].z);
+            camRight = hm::rotate(q, hm::V3(1.f, 0.f, 0.f));
+            camUp = hm::rotate(q, hm::V3(0.f, 1.f, 0.f));
+            camFwd = hm::rotate(q, hm::V3(0.f, 0.f, -1.f));
+        }
+    } else {
+        for (size_t i = 0; i < transitions.size(); ++i)  // main.cpp:1022-1026
+            for (size_t child : children[i]) transitions[child] = transitions[i] * transitions[child];
+    }
 
     out.tri_verts.clear();
     out.tri_material.clear();
@@ -239,10 +316,11 @@ void load(const std::string &path, uint32_t width, uint32_t height, rt_host_scen
             const std::vector<char> &bp = buffers[vp.buffer];
             if (ap.type != "VEC3") throw std::runtime_error("Unsupported accessor type, expected VEC3");
             const size_t offset = vp.byteOffset + ap.byteOffset;
+            const size_t stride = vp.byteStride ? vp.byteStride : 12;  // byteStride is 0 unless RT_GLTF_STRIDE
             std::vector<hm::vec3> points(ap.count);
             for (size_t j = 0; j < ap.count; ++j)
-                points[j] = hm::V3(read_f32(bp, offset + 12 * j), read_f32(bp, offset + 12 * j + 4),
-                                   read_f32(bp, offset + 12 * j + 8));
+                points[j] = hm::V3(read_f32(bp, offset + stride * j), read_f32(bp, offset + stride * j + 4),
+                                   read_f32(bp, offset + stride * j + 8));
 
             const Accessor &ai = accessors[prim.indices];
             const BufferView &vi = views[ai.bufferView];
@@ -253,11 +331,12 @@ void load(const std::string &path, uint32_t width, uint32_t height, rt_host_scen
             else if (ai.componentType == 5125) iw = 4;
             else throw std::runtime_error("Unsupported accessor component type, expected 5123 or 5125");
 
+            const size_t indexBase = vi.byteOffset + ((flags & RT_GLTF_INDEX_OFFSET) ? ai.byteOffset : 0);
             const hm::mat4 &m = transitions[i];
-            for (size_t j = 0; j < ai.count; j += 3) {
+            for (size_t j = 0; j + 2 < ai.count; j += 3) {
                 size_t idx[3];
                 for (size_t k = 0; k < 3; ++k) {
-                    idx[k] = read_index(bi, vi.byteOffset + iw * (j + k), iw);
+                    idx[k] = read_index(bi, indexBase + iw * (j + k), iw);
                     if (idx[k] >= points.size()) throw std::runtime_error("vertex index out of range");
                 }
                 for (size_t k = 0; k < 3; ++k) {
@@ -288,8 +367,12 @@ void load(const std::string &path, uint32_t width, uint32_t height, rt_host_scen
 extern "C" {
 
 int rt_gltf_load(const char *path, uint32_t width, uint32_t height, rt_host_scene **out) {
-    if (!path || !out || width == 0 || height == 0) {
-        rt::set_error("rt_gltf_load: null argument or zero image size");
+    return rt_gltf_load_ex(path, width, height, 0u, out);
+}
+
+int rt_gltf_load_ex(const char *path, uint32_t width, uint32_t height, uint32_t flags, rt_host_scene **out) {
+    if (!path || !out || width == 0 || height == 0 || (flags & ~(uint32_t)RT_GLTF_SPEC)) {
+        rt::set_error("rt_gltf_load: null argument, zero image size or unknown flag");
         return RT_ERR_INVALID;
     }
     *out = nullptr;
@@ -297,7 +380,7 @@ int rt_gltf_load(const char *path, uint32_t width, uint32_t height, rt_host_scen
     rt_host_scene *hs = nullptr;
     try {
         hs = new rt_host_scene();
-        load(path, width, height, *hs);
+        load(path, width, height, flags, *hs);
     } catch (const std::exception &e) {
         delete hs;
         rt::set_error(std::string("rt_gltf_load: ") + e.what());

@@ -11,6 +11,7 @@
 //     --seed S         seed of the counter RNG (default 0)
 //     --device D       GPU index (default 0)
 //     --dump-hits F    also write the primary-ray closest hits (uint32 id, float t per pixel) to F
+//     --gltf-spec      read the scene by the glTF 2.0 rules the reference does not follow (RT_GLTF_SPEC)
 // All rendering runs on the GPU through the C ABI of librt_amd.so; there is no CPU fallback.
 #include <chrono>
 #include <cstdio>
@@ -35,7 +36,7 @@ int main(int argc, char *argv[]) {
     if (argc < 6) {
         std::fprintf(stderr,
                      "usage: %s <scene.gltf> <width> <height> <samples> <output.ppm> [--depth N] [--rng reference|counter]"
-                     " [--pipeline mega|wavefront] [--seed S] [--device D] [--dump-hits FILE]\n",
+                     " [--pipeline mega|wavefront] [--seed S] [--device D] [--dump-hits FILE] [--gltf-spec]\n",
                      argv[0]);
         return 2;
     }
@@ -45,7 +46,7 @@ int main(int argc, char *argv[]) {
         std::fprintf(stderr, "raytracing: width, height and samples must be positive (width/height at most 65535)\n");
         return 2;
     }
-    uint32_t depth = 6, seed = 0;
+    uint32_t depth = 6, seed = 0, gltfFlags = 0;
     int rng = RT_RNG_REFERENCE, pipeline = RT_PIPE_MEGAKERNEL, device = 0;
     std::string dumpHits;
     for (int i = 6; i < argc; ++i) {
@@ -61,6 +62,7 @@ int main(int argc, char *argv[]) {
         else if (a == "--seed") seed = (uint32_t)std::strtoul(need("--seed"), nullptr, 0);
         else if (a == "--device") device = std::atoi(need("--device"));
         else if (a == "--dump-hits") dumpHits = need("--dump-hits");
+        else if (a == "--gltf-spec") gltfFlags = RT_GLTF_SPEC;
         else if (a == "--rng") {
             std::string v = need("--rng");
             if (v == "reference") rng = RT_RNG_REFERENCE;
@@ -84,7 +86,8 @@ int main(int argc, char *argv[]) {
     }
 
     rt_host_scene *hs = nullptr;
-    if (rt_gltf_load(inputPath.c_str(), (uint32_t)width, (uint32_t)height, &hs) != RT_OK) return die("loading the scene");
+    if (rt_gltf_load_ex(inputPath.c_str(), (uint32_t)width, (uint32_t)height, gltfFlags, &hs) != RT_OK)
+        return die("loading the scene");
     rt_scene_desc desc;
     rt_host_scene_get_desc(hs, &desc);
     rt_scene *scene = nullptr;

@@ -274,3 +274,78 @@ def test_cli_usage_and_gpu_requirement(scene_dir):
         with pytest.raises(rt.RtError) as e:
             rt.Scene(rt.load_gltf(make_scene(scene_dir, "cornell"), 32, 24))
         assert e.value.code == -3
+
+
+def _write_two_triangle_scene(tmp_path, variant):
+    """Two triangles under a parent/child node pair and a camera under a translated parent, laid out
+    either the way the reference's loader reads files ("plain") or with features only the opt-in
+    flags understand: interleaved positions (byteStride 24), two index accessors sharing a bufferView
+    through accessor.byteOffset, a base64 buffer, children listed before their parents."""
+    import base64
+    import json
+    import struct
+    pos = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0.5)]
+    idx_a, idx_b = (0, 1, 2), (1, 3, 2)
+    if variant == "plain":
+        blob = b"".join(struct.pack("<3f", *p) for p in pos) + struct.pack("<3H", *idx_a) + b"\0\0" + struct.pack("<3H", *idx_b) + b"\0\0"
+        views = [dict(buffer=0, byteOffset=0, byteLength=48), dict(buffer=0, byteOffset=48, byteLength=6),
+                 dict(buffer=0, byteOffset=56, byteLength=6)]
+        accessors = [dict(bufferView=0, componentType=5126, count=4, type="VEC3"),
+                     dict(bufferView=1, componentType=5123, count=3, type="SCALAR"),
+                     dict(bufferView=2, componentType=5123, count=3, type="SCALAR")]
+    else:
+        blob = b"".join(struct.pack("<6f", *p, 0.0, 0.0, 1.0) for p in pos) + struct.pack("<3H", *idx_a) + b"\0\0" + struct.pack("<3H", *idx_b) + b"\0\0"
+        views = [dict(buffer=0, byteLength=96, byteStride=24), dict(buffer=0, byteOffset=96, byteLength=16)]
+        accessors = [dict(bufferView=0, componentType=5126, count=4, type="VEC3"),
+                     dict(bufferView=1, componentType=5123, count=3, type="SCALAR"),
+                     dict(bufferView=1, byteOffset=8, componentType=5123, count=3, type="SCALAR")]
+    mat = dict(pbrMetallicRoughness=dict(metallicFactor=0.0, baseColorFactor=[0.5, 0.5, 0.5, 1.0]))
+    meshes = [dict(primitives=[dict(attributes=dict(POSITION=0), indices=1, material=0)]),
+              dict(primitives=[dict(attributes=dict(POSITION=0), indices=2, material=0)])]
+    parent = dict(translation=[1.0, 2.0, 3.0], scale=[2.0, 2.0, 2.0])
+    child_a = dict(mesh=0, translation=[0.5, 0.0, 0.0])
+    child_b = dict(mesh=1, rotation=[0.0, 0.0, 0.70710678, 0.70710678])
+    rig = dict(translation=[0.0, 1.0, 5.0])
+    cam = dict(camera=0, translation=[0.0, 0.0, 1.0])
+    if variant == "plain":      # parents before children, as the reference needs them
+        nodes = [dict(parent, children=[1, 2]), child_a, child_b, dict(rig, children=[4]), cam]
+    else:                       # children first
+        nodes = [child_a, child_b, dict(parent, children=[0, 1]), cam, dict(rig, children=[3])]
+    uri = "two.bin"
+    if variant == "spec":
+        uri = "data:application/octet-stream;base64," + base64.b64encode(blob).decode()
+    else:
+        (tmp_path / "two.bin").write_bytes(blob)
+    doc = dict(asset=dict(version="2.0"), buffers=[dict(uri=uri, byteLength=len(blob))], bufferViews=views,
+               accessors=accessors, materials=[mat], meshes=meshes, nodes=nodes,
+               cameras=[dict(type="perspective", perspective=dict(yfov=0.8, znear=0.1))])
+    path = tmp_path / ("two_%s.gltf" % variant)
+    path.write_text(json.dumps(doc))
+    return str(path)
+
+
+def test_gltf_spec_flags(tmp_path):
+    """rt_gltf_load_ex: the opt-in glTF 2.0 rules (stride, index accessor offset, data URI, hierarchy in
+    any node order, camera under a parent).  The same geometry written the reference's way and the
+    specification's way must load to the same triangles; without the flags the second file is read
+    by the reference's rules and comes out different (or is rejected)."""
+    import raytracing_amd as rt
+    plain = rt.load_gltf(_write_two_triangle_scene(tmp_path, "plain"), 64, 48)
+    spec_path = _write_two_triangle_scene(tmp_path, "spec")
+    spec = rt.load_gltf(spec_path, 64, 48, flags=rt.api.GLTF_SPEC)
+    assert plain.tri_verts.shape == (2, 3, 3)
+    order = np.argsort(spec.tri_verts[:, 0, 0] * 7 + spec.tri_verts[:, 1, 1])
+    order_p = np.argsort(plain.tri_verts[:, 0, 0] * 7 + plain.tri_verts[:, 1, 1])
+    assert np.array_equal(spec.tri_verts[order], plain.tri_verts[order_p])       # same transforms, same bits
+    # parent (T, S=2) * child translation (0.5, 0, 0): vertex (0,0,0) of mesh 0 lands at (2, 2, 3)
+    assert any(np.allclose(v, [2.0, 2.0, 3.0]) for v in plain.tri_verts.reshape(-1, 3))
+    # the reference's rules put the camera at its local translation; the hierarchy flag adds the rig's
+    assert np.allclose(plain.camera["position"], [0.0, 0.0, 1.0])
+    assert np.allclose(spec.camera["position"], [0.0, 1.0, 6.0])
+    same_rules = rt.load_gltf(_write_two_triangle_scene(tmp_path, "plain"), 64, 48, flags=rt.api.GLTF_SPEC)
+    assert np.array_equal(same_rules.tri_verts, plain.tri_verts)                 # flags do not disturb a plain file
+    assert np.allclose(same_rules.camera["position"], [0.0, 1.0, 6.0])
+    with pytest.raises(rt.RtError):                                             # reference rules: byteOffset is required
+        rt.load_gltf(spec_path, 64, 48)
+    with pytest.raises(rt.RtError):
+        rt.load_gltf(spec_path, 64, 48, flags=0x100)                             # unknown flag
