@@ -96,6 +96,47 @@ def test_far_origin_rays_bit_exact(scene_dir, oracle_mod):
     assert (ids_g != 0xFFFFFFFF).sum() > 0.5 * n
 
 
+@pytest.mark.parametrize("seed,extent,offset", [(1, 0.05, 0.0), (2, 2.0, 50.0), (3, 150.0, 0.0), (4, 1.0, -99.0)])
+def test_random_triangle_soups_bit_exact(oracle_mod, seed, extent, offset):
+    """Triangle soups of mixed sizes (edges from 1e-4 to the whole extent, some degenerate, some
+    duplicated, some axis-aligned) at different scales and positions inside [-100, 100]^3, against the
+    oracle's brute-force loop over all triangles: stresses the 16-bit node grid and its guard cells."""
+    import raytracing_amd as rt
+    rng = np.random.RandomState(seed)
+    n = 3000
+    centre = rng.uniform(-0.5, 0.5, size=(n, 1, 3)) * extent + offset
+    size = (10.0 ** rng.uniform(-4, 0, size=(n, 1, 1))) * extent
+    tri = centre + rng.uniform(-0.5, 0.5, size=(n, 3, 3)) * size
+    tri[:100, :, rng.randint(0, 3)] = tri[:100, :1, 0]            # axis-aligned (flat boxes)
+    tri[100:130, 2] = tri[100:130, 1]                             # zero area
+    tri[130:160] = tri[160:190]                                   # duplicates: exact distance ties
+    tri = np.clip(tri, -100.0, 100.0).astype(np.float32)
+    mats = np.zeros(1, dtype=rt.api.MATERIAL_DTYPE)
+    mats["color"] = 0.5
+    cam = dict(position=[0, 0, 0], right=[1, 0, 0], up=[0, 1, 0], forward=[0, 0, -1], tan_x=1, tan_y=1)
+    host = rt.HostScene(tri, np.zeros(n, np.uint32), mats, cam)
+    gpu = rt.Scene(host, device=0)
+    orc = oracle_mod.OracleScene(tri, np.zeros(n, np.uint32), mats, cam)
+    m = 30000
+    o = (rng.uniform(-0.8, 0.8, size=(m, 3)) * extent + offset).astype(np.float32)
+    target = tri[rng.randint(0, n, m)]
+    w = rng.dirichlet([1, 1, 1], size=m).astype(np.float32)
+    w[: m // 6] = np.eye(3, dtype=np.float32)[rng.randint(0, 3, m // 6)]      # aimed exactly at a vertex
+    w[m // 6: m // 3, 0] = 0                                                   # aimed at an edge
+    w /= w.sum(axis=1, keepdims=True)
+    p = (target * w[:, :, None]).sum(axis=1)
+    d = p - o
+    d[m // 2:] = rng.normal(size=(m - m // 2, 3))                              # unaimed
+    d = (d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)).astype(np.float32)
+    ids_o, t_o, tie, _ = orc.intersect(o, d, use_bvh=False)
+    ids_g, t_g = gpu.intersect(o, d)
+    ok = ~np.isnan(t_o)                                            # zero-determinant "hits" of the reference: see below
+    _compare_hits(ids_g[ok], t_g[ok], ids_o[ok], t_o[ok], tie[ok])
+    assert (ids_g != 0xFFFFFFFF).sum() > 0.3 * m
+    gpu.close()
+    orc.close()
+
+
 def test_axis_parallel_rays_are_finite(scene_dir, oracle_mod):
     """Rays exactly parallel to a triangle's plane make the reference's 3x3 inverse divide by a
     zero determinant; it then accepts a NaN-distance "hit" whenever that triangle is the first
