@@ -438,3 +438,40 @@ def test_light_tree_matches_the_loop_over_all_lights(scene_dir, oracle_mod, monk
         assert c["segments"] == c_c["segments"]
         if name == "emissive":   # the point of the tree: far fewer exact light tests than lights x vertices
             assert c["light_tests"] < 0.05 * c_c["light_tests"]
+
+
+@pytest.mark.parametrize("seed,n_emissive", [(5, 6), (6, 200)])
+def test_random_material_soup_renders_bit_exact(oracle_mod, seed, n_emissive):
+    """A soup of 700 random triangles with all three material types and `n_emissive` emissive ones
+    scattered through it: with 200 lights a sampled direction often crosses more than four of them,
+    which exercises the light tree's repeated walks (terms must still be added in light-list
+    order); with 6 the LDS loop runs.  Reference-RNG sums bit for bit, counter-RNG kernels within 1e-5."""
+    import raytracing_amd as rt
+    rng = np.random.RandomState(seed)
+    n = 700
+    centre = rng.uniform(-1.0, 1.0, size=(n, 1, 3))
+    tri = (centre + rng.uniform(-0.35, 0.35, size=(n, 3, 3))).astype(np.float32)
+    mats = np.zeros(5, dtype=rt.api.MATERIAL_DTYPE)
+    mats["color"] = [[0.7, 0.6, 0.5], [0.9, 0.9, 0.9], [0.95, 1.0, 0.97], [0.8, 0.8, 0.8], [0.3, 0.4, 0.8]]
+    mats["type"] = [0, 1, 2, 0, 0]
+    mats["ior"] = 1.5
+    mats["emission"][3] = [4.0, 3.5, 3.0]
+    which = rng.choice([0, 1, 2, 4], size=n, p=[0.5, 0.2, 0.2, 0.1]).astype(np.uint32)
+    which[rng.choice(n, n_emissive, replace=False)] = 3
+    cam = dict(position=[0.0, 0.0, 4.0], right=[1, 0, 0], up=[0, 1, 0], forward=[0, 0, -1], tan_x=0.5, tan_y=0.375)
+    host = rt.HostScene(tri, which, mats, cam)
+    gpu = rt.Scene(host, device=0)
+    orc = oracle_mod.OracleScene(tri, which, mats, cam)
+    assert gpu.stats()["nlights"] == n_emissive
+    W, H, spp, depth = 64, 48, 3, 6
+    ref, _ = orc.render(W, H, spp, max_depth=depth, rng_mode=0)
+    _assert_bits_equal(gpu.render(W, H, spp, max_depth=depth, rng_mode=rt.RNG_REFERENCE), ref)
+    assert ref.sum() > 0
+    ref_c, c_c = orc.render(W, H, spp, max_depth=depth, rng_mode=1, seed=9)
+    for pipe in (rt.PIPE_MEGAKERNEL, rt.PIPE_WAVEFRONT):
+        gpu.reset_counters()
+        out_c = gpu.render(W, H, spp, max_depth=depth, rng_mode=rt.RNG_COUNTER, seed=9, pipeline=pipe)
+        _assert_close(out_c, ref_c)
+        assert gpu.counters()["segments"] == c_c["segments"]
+    gpu.close()
+    orc.close()
