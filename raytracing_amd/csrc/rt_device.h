@@ -17,7 +17,7 @@ constexpr float kInf = 10000.f;    // INF, main.cpp:23
 constexpr float kOneOverPi = 0.318309886183790671537767526745028724f;  // glm::one_over_pi<float>()
 constexpr int kBlock = 256;        // threads per workgroup of every traversal kernel (4 waves)
 constexpr int kStack = 24;         // traversal stack entries per lane, all in LDS (host checks tree height)
-constexpr int kExitLanes = 12;     // wf_extend: node phase ends when this few walking lanes still lack a leaf
+constexpr int kExitLanes = 28;     // wf_extend: node phase ends when this few walking lanes still lack a leaf
 constexpr int kCounterShards = 256;   // statistics counters: shards (power of two) ...
 constexpr int kCounterStride = 16;    // ... of 16 x u64 = one 128-byte line each
 
@@ -339,11 +339,15 @@ struct Traversal {
             // Leave the node phase once at most EXIT_LANES of the lanes still walking hold no leaf yet:
             // for incoherent rays, waiting for the last few stragglers kept most of the wave idle (lane
             // occupancy of this phase was 44 %); they simply resume after the triangle phase.  Queue
-            // tracing, million-triangle workload: 0 (= wait for all) 2445, 4: 2673, 12: 2681, 24: 2623
-            // Mrays/s.  Coherent camera rays and the megakernel lose 8-9 % with 12, so they use 0.
+            // tracing, million-triangle workload, with one leaf per round: 4: 3733, 12: 3849, 20: 3959,
+            // 28: 3995, 32: 3989, 40: 3949, 48: 3753, 63: 2872 Mrays/s (Cornell and the glass scene are flat
+            // from 4 to 32).  The megakernel and the primary-ray kernels lose 8-9 % with 12, so they use 0.
             if (__builtin_popcountll(__ballot(leaf == 0)) <= EXIT_LANES) break;
         }
-        while (leaf != 0) {
+        // One leaf per round: a lane whose `cur` is a leaf too keeps it for the next round instead of making
+        // the wave loop here for the few lanes in that state (queue tracing +2 % on the million-triangle
+        // scene, +5 % on the Cornell box; the megakernel loses 2 %).
+        if (leaf != 0) {
             const uint32_t ref = ~(uint32_t)leaf;
             const uint32_t first = ref >> 3, cnt = (ref & 7u) + 1u;
             for (uint32_t k = 0; k < cnt; ++k) {
