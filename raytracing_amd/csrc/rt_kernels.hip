@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void wf_generate(DevScene S, rt::RenderPara
 // and moves on to the next shard when one runs dry.  Eight cursors take eight times the atomics, which
 // lets the chunk be 128 rays.
 constexpr uint32_t kChunk = 128;  // 64: -1 %, 256: -2 %, 512: -5 % (million-triangle scene); Cornell flat from 128 up
-constexpr int kRefill = 12;  // insensitive: 4 / 12 / 24 / 32 idle lanes all within 1 %
+constexpr int kRefill = 20;  // 4: -3 %, 12: -1 %, 16 to 24: within 0.5 %, 32: -2 %
 
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const uint32_t *__restrict__ queue,
