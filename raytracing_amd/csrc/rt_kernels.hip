@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kBlock) void k_render_replay(DevScene S, rt::Render
 
 // ---------------------------------------------------------------------------------------------
 // Wavefront pipeline.  Path record i lives at slot i of the record arrays for its whole life;
-// queues hold the slot indices still alive.  Slot i renders pixel i % npix, sample
+// queues hold the slot indices still alive.  Slot i renders pixel frame_pixel(i % npix), sample
 // spp0 + i / npix.
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kShards = 8;           // work cursors of wf_extend (see there)
