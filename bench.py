@@ -206,7 +206,7 @@ def main():
     cpu = None
     if not args.no_cpu_baseline and world == 1:  # reported once, by the single-GPU run
         from oracle import oracle
-        cw, ch, cspp = W // 4, H // 4, 4
+        cw, ch, cspp = W // 2, H // 2, 12   # about 10 s of wall time on 16 host threads for the default workload
         host_small = rt.load_gltf(path, cw, ch).as_dict()
         tb = time.perf_counter()
         orc = oracle.OracleScene(host_small["tri_verts"], host_small["tri_material"], host_small["materials"],
