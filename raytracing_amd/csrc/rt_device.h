@@ -17,7 +17,7 @@ constexpr float kInf = 10000.f;    // INF, main.cpp:23
 constexpr float kOneOverPi = 0.318309886183790671537767526745028724f;  // glm::one_over_pi<float>()
 constexpr int kBlock = 256;        // threads per workgroup of every traversal kernel (4 waves)
 constexpr int kStack = 24;         // traversal stack entries per lane, all in LDS (host checks tree height)
-constexpr int kExitLanes = 28;     // wf_extend: node phase ends when this few walking lanes still lack a leaf
+constexpr int kExitLanes = 32;     // wf_extend: node phase ends when this few walking lanes still lack a leaf
 constexpr int kCounterShards = 256;   // statistics counters: shards (power of two) ...
 constexpr int kCounterStride = 16;    // ... of 16 x u64 = one 128-byte line each
 
@@ -223,7 +223,7 @@ __device__ __forceinline__ bool tri_test(float4 q0, float4 q1, float4 q2, v3 o, 
 // height bound (kStack inner levels) is what keeps the stack from overflowing.
 constexpr int kSentinel = 0x7FFFFFFF;  // "stack is empty": never a node index, never a leaf reference
 
-template <bool COUNT, int EXIT_LANES = 0>
+template <bool COUNT, int EXIT_LANES = 0, bool HELP = false>
 struct Traversal {
     struct f2 {
         float x, y;
@@ -238,6 +238,7 @@ struct Traversal {
     int leaf;  // postponed leaf reference (< 0) or 0 = none
     int sp;
     int *stack;   // this lane's column of the LDS stack
+    uint32_t *xchg;  // HELP: 128 words of LDS owned by this wave
 
     // lane_stack: &lds[threadIdx.x]
     __device__ __forceinline__ void bind(int *lane_stack) { stack = lane_stack; }
@@ -341,33 +342,95 @@ struct Traversal {
             // occupancy of this phase was 44 %); they simply resume after the triangle phase.  Queue
             // tracing, million-triangle workload, with one leaf per round: 4: 3733, 12: 3849, 20: 3959,
             // 28: 3995, 32: 3989, 40: 3949, 48: 3753, 63: 2872 Mrays/s (Cornell and the glass scene are flat
-            // from 4 to 32).  The megakernel and the primary-ray kernels lose 8-9 % with 12, so they use 0.
+            // from 4 to 32); with helper lanes in the triangle round 20: 4213, 28: 4308, 36: 4308, 44: 4201.  The megakernel and the primary-ray kernels lose 8-9 % with 12, so they use 0.
             if (__builtin_popcountll(__ballot(leaf == 0)) <= EXIT_LANES) break;
         }
         // One leaf per round: a lane whose `cur` is a leaf too keeps it for the next round instead of making
         // the wave loop here for the few lanes in that state (queue tracing +2 % on the million-triangle
         // scene, +5 % on the Cornell box; the megakernel loses 2 %).
-        if (leaf != 0) {
-            const uint32_t ref = ~(uint32_t)leaf;
-            const uint32_t first = ref >> 3, cnt = (ref & 7u) + 1u;
-            for (uint32_t k = 0; k < cnt; ++k) {
-                const float4 *tp = S.tris + 4 * (size_t)(first + k);
-                float t;
-                if (COUNT) ++st.tris;
-                if (tri_test(tp[0], tp[1], tp[2], o, d, t) && t < tBest) {
-                    tBest = t;
-                    triBest = (int)(first + k);
+        if (!HELP) {
+            if (leaf != 0) {
+                const uint32_t ref = ~(uint32_t)leaf;
+                const uint32_t first = ref >> 3, cnt = (ref & 7u) + 1u;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const float4 *tp = S.tris + 4 * (size_t)(first + k);
+                    float t;
+                    if (COUNT) ++st.tris;
+                    if (tri_test(tp[0], tp[1], tp[2], o, d, t) && t < tBest) {
+                        tBest = t;
+                        triBest = (int)(first + k);
+                    }
+                }
+                leaf = 0;
+                if (cur < 0) {
+                    leaf = cur;
+                    cur = pop();
                 }
             }
-            leaf = 0;
-            if (cur < 0) {
-                leaf = cur;
-                cur = pop();
+        } else {
+            // Lanes without a leaf lend a hand: a two-triangle leaf's second triangle is tested by an idle
+            // lane with the owner's ray, in the same pass as everybody's first triangle, and the owner
+            // merges the distance afterwards (after its own, so ties fall as in the sequential order).
+            const uint32_t lane = threadIdx.x & 63u;
+            const bool has = leaf != 0;
+            const uint32_t ref = ~(uint32_t)leaf;
+            const uint32_t first = ref >> 3, cnt = has ? (ref & 7u) + 1u : 0u;
+            const unsigned long long donors = __ballot(cnt == 2u), helpers = __ballot(!has);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const uint32_t npair = (uint32_t)min(__builtin_popcountll(donors), __builtin_popcountll(helpers));
+            const uint32_t drank = (uint32_t)__builtin_popcountll(donors & below);
+            const uint32_t hrank = (uint32_t)__builtin_popcountll(helpers & below);
+            const bool lend = cnt == 2u && drank < npair, help = !has && hrank < npair;
+            if (lend) xchg[drank] = lane;
+            __builtin_amdgcn_wave_barrier();  // LDS serves a wave's operations in order; keep the compiler from moving them
+            int src = (int)lane;
+            if (help) src = (int)xchg[hrank];
+            const v3 ro = mk(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
+            const v3 rd = mk(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
+            float t = kInf;
+            bool hit = false;
+            const uint32_t firstOfSrc = (uint32_t)__shfl((int)first, src);  // every lane takes part in the shuffle
+            const uint32_t myTri = has ? first : firstOfSrc + 1u;
+            if (has || help) {
+                const float4 *tp = S.tris + 4 * (size_t)myTri;
+                hit = tri_test(tp[0], tp[1], tp[2], ro, rd, t);
+            }
+            if (help) xchg[64 + hrank] = __float_as_uint(hit ? t : kInf);
+            __builtin_amdgcn_wave_barrier();
+            if (COUNT) {  // passes of the wave through the triangle test: one, two if a second triangle found no helper
+                const uint32_t passes = (has ? 1u : 0u) + ((cnt == 2u && !lend) ? 1u : 0u);
+                st.triWave += wave_max(passes);
+            }
+            if (has) {
+                if (COUNT) st.tris += cnt;
+                if (hit && t < tBest) {
+                    tBest = t;
+                    triBest = (int)first;
+                }
+                if (lend) {
+                    const float t2 = __uint_as_float(xchg[64 + drank]);
+                    if (t2 < tBest) {
+                        tBest = t2;
+                        triBest = (int)first + 1;
+                    }
+                } else if (cnt == 2u) {  // more two-triangle leaves than idle lanes: test it here
+                    const float4 *tp = S.tris + 4 * (size_t)(first + 1u);
+                    float t2;
+                    if (tri_test(tp[0], tp[1], tp[2], o, d, t2) && t2 < tBest) {
+                        tBest = t2;
+                        triBest = (int)first + 1;
+                    }
+                }
+                leaf = 0;
+                if (cur < 0) {
+                    leaf = cur;
+                    cur = pop();
+                }
             }
         }
         if (COUNT) {  // all lanes of the wave are converged here
             st.nodeWave += wave_max(st.nodes - nodes0);
-            st.triWave += wave_max(st.tris - tris0);
+            if (!HELP) st.triWave += wave_max(st.tris - tris0);
         }
     }
 };

@@ -272,9 +272,11 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
     const uint32_t count = *qcount_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) *qcount_zero = 0u;  // the queue the next shade pass fills
     const uint32_t lane = threadIdx.x & 63u;
-    Traversal<COUNT, kExitLanes> T;
+    __shared__ uint32_t s_xchg[4][128];
+    Traversal<COUNT, kExitLanes, true> T;
     T.idle();
     T.bind(s_stack + threadIdx.x);
+    T.xchg = s_xchg[threadIdx.x >> 6];
     uint32_t slot = 0, segs = 0;
     bool hasRay = false;
     uint32_t chunkNext = 0, chunkEnd = 0;  // wave-uniform
