@@ -63,6 +63,12 @@ extern "C" {
 #define RT_PIPE_MEGAKERNEL 0
 #define RT_PIPE_WAVEFRONT 1
 
+/* Limits of the acceleration structure: leaves hold at most 2 triangles and the tree has at most
+ * RT_MAX_TREE_HEIGHT inner levels (the per-lane traversal stack of the kernels), so a scene holds at
+ * most 2 * 2^24 triangles; rt_scene_create / rt_flat_build return RT_ERR_LIMIT beyond that. */
+#define RT_MAX_TREE_HEIGHT 24
+#define RT_MAX_TRIANGLES (2u << RT_MAX_TREE_HEIGHT)
+
 #define RT_MISS_ID 0xFFFFFFFFu /* prim_id of a ray that hits nothing */
 #define RT_INF 10000.0f        /* t of a ray that hits nothing (INF, main.cpp:23) */
 
@@ -106,7 +112,13 @@ typedef struct rt_scene_stats {
     uint32_t nnodes;      /* 32-byte two-child nodes */
     uint32_t tree_height; /* inner-node levels on the longest root-to-leaf path */
     double build_seconds; /* host BVH build + flatten */
-    uint64_t device_bytes;
+    uint64_t device_bytes; /* device memory the scene holds now (grows with rt_scene_reserve / first renders) */
+    /* Splits of the main tree where the height bound (RT_MAX_TREE_HEIGHT inner levels = the kernels'
+     * traversal stack) ruled out the cheapest surface-area-heuristic candidate, or every candidate
+     * (median split).  0 = the bound cost nothing; large values mean a deeper, worse tree than the
+     * heuristic wanted, i.e. the scene is close to the triangle limit. */
+    uint32_t height_capped_splits;
+    uint32_t reserved_;
 } rt_scene_stats;
 
 /* Counters accumulated on the device by the launches since the last rt_counters_reset:
@@ -204,6 +216,14 @@ int rt_render(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_begin, 
 int rt_render_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_begin, uint32_t spp_count,
                   uint32_t max_depth, int rng_mode, uint32_t seed, int pipeline, float *d_radiance_sum,
                   void *stream);
+/* Scratch of the render calls (no reference counterpart: the CPU path keeps its state on the stack).
+ * The wavefront pipeline keeps 72 bytes per path in flight (up to 64 frames of samples or 128 Mi
+ * paths, never more than spp_count frames), the reference-RNG mode 12 bytes per pixel and bounce.
+ * rt_scene_reserve allocates them for the given call shape; buffers only grow and live until
+ * rt_scene_destroy.  rt_render_dev on a scene whose scratch already covers the call only enqueues;
+ * otherwise it first does what rt_scene_reserve does (waits for the device, allocates). */
+int rt_scene_reserve(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_count, uint32_t max_depth,
+                     int rng_mode, int pipeline);
 
 /* ---- image: mean, ACES, gamma (main.cpp:1226-1231, 827-838), truncating byte conversion
  * (colorFloatToInt, main.cpp:840-846), PPM writer (printImage, main.cpp:856-864) ---- */
@@ -237,6 +257,15 @@ typedef struct rt_kernel_times {
 } rt_kernel_times;
 int rt_set_timing(rt_scene *s, int enable);
 int rt_timing_read(rt_scene *s, rt_kernel_times *out);
+
+/* Self-test of the device's restatements of the RNG helpers (sampleUInt / sampleUniform /
+ * sampleNormal over std::minstd_rand, main.cpp:98-111): engine k is seeded with seeds[k] as
+ * generatePixel seeds its engine (main.cpp:1221) and produces n values per output, stored at
+ * [k * n + i].  what = 0: per i one sampleUniform(), one sampleNormal(), one sampleUInt(0, nlights-1)
+ * in that order from the one engine; 1 / 2 / 3: only uniforms / normals / uints; 4: raw engine
+ * outputs (in ui).  Host pointers, each nseeds * n long; arrays a mode does not produce are zeroed. */
+int rt_selftest_rng(int device, const uint32_t *seeds, uint32_t nseeds, uint32_t n, uint32_t nlights, int what,
+                    float *uni, float *nrm, uint32_t *ui);
 
 /* The seed of the per-(pixel, sample) stream of RT_RNG_COUNTER (host helper for checkers). */
 uint32_t rt_counter_seed(uint32_t pixel, uint32_t sample, uint32_t seed);

@@ -34,7 +34,8 @@ class SceneDesc(C.Structure):
 
 class SceneStats(C.Structure):
     _fields_ = [("ntri", C.c_uint32), ("nlights", C.c_uint32), ("nnodes", C.c_uint32), ("tree_height", C.c_uint32),
-                ("build_seconds", C.c_double), ("device_bytes", C.c_uint64)]
+                ("build_seconds", C.c_double), ("device_bytes", C.c_uint64), ("height_capped_splits", C.c_uint32),
+                ("reserved_", C.c_uint32)]
 
 
 class Counters(C.Structure):
@@ -74,6 +75,9 @@ SIGNATURES = {
                             C.c_uint32, C.c_int, C.c_void_p]),
     "rt_render_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                 C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
+    "rt_scene_reserve": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
+    "rt_selftest_rng": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
     "rt_tonemap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
     "rt_tonemap_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                  C.c_void_p]),

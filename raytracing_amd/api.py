@@ -158,7 +158,8 @@ class Scene:
         s = _lib.SceneStats()
         check(_lib.lib().rt_scene_get_stats(self._h, C.byref(s)))
         return dict(ntri=s.ntri, nlights=s.nlights, nnodes=s.nnodes, tree_height=s.tree_height,
-                    build_seconds=s.build_seconds, device_bytes=int(s.device_bytes))
+                    build_seconds=s.build_seconds, device_bytes=int(s.device_bytes),
+                    height_capped_splits=s.height_capped_splits)
 
     def flat(self):
         st = self.stats()
@@ -230,6 +231,11 @@ class Scene:
                                        int(rng_mode), int(seed), int(pipeline), C.c_void_p(radiance_sum_ptr),
                                        _stream_ptr(stream)))
 
+    def reserve(self, width, height, spp, max_depth=6, rng_mode=RNG_COUNTER, pipeline=PIPE_WAVEFRONT):
+        """Allocate the scratch a render of this shape needs, so that render_dev only enqueues."""
+        check(_lib.lib().rt_scene_reserve(self._h, int(width), int(height), int(spp), int(max_depth), int(rng_mode),
+                                          int(pipeline)))
+
     # -- image (main.cpp:1226-1231, 840-846) -------------------------------------------------
     def tonemap(self, radiance_sum, spp):
         rs = np.ascontiguousarray(radiance_sum, dtype=np.float32).reshape(-1, 3)
@@ -282,6 +288,16 @@ def generate_scene(input_data, rng_mode=RNG_REFERENCE, pipeline=PIPE_MEGAKERNEL,
 def print_image(scene_float, path):
     rgb = np.ascontiguousarray(scene_float.rgb8, dtype=np.uint8)
     check(_lib.lib().rt_write_ppm(str(path).encode(), int(scene_float.width), int(scene_float.height), _p(rgb)))
+
+
+def selftest_rng(seeds, n, nlights=2, what=0, device=0):
+    """Runs the device's RNG restatements: returns (uniforms, normals, uints), each (len(seeds), n)."""
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+    shape = (seeds.shape[0], int(n))
+    uni, nrm, ui = np.empty(shape, np.float32), np.empty(shape, np.float32), np.empty(shape, np.uint32)
+    check(_lib.lib().rt_selftest_rng(int(device), _p(seeds), seeds.shape[0], int(n), int(nlights), int(what), _p(uni),
+                                     _p(nrm), _p(ui)))
+    return uni, nrm, ui
 
 
 def counter_seed(pixel, sample, seed):

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
+#include <string>
 
 #include <omp.h>
 
@@ -78,6 +79,7 @@ struct Builder {
     std::vector<Prim> prims;
     std::vector<BNode> nodes;
     std::atomic<uint32_t> next{0};
+    std::atomic<uint32_t> capped{0};  // splits where the height bound changed the outcome
 
     uint32_t alloc() { return next.fetch_add(1, std::memory_order_relaxed); }
 
@@ -96,7 +98,7 @@ struct Builder {
         cb.reset();
         for (uint32_t i = b; i < e; ++i) cb.grow(prims[i].c);
 
-        float bestCost = 3.0e38f;
+        float bestCost = 3.0e38f, freeCost = 3.0e38f;  // cheapest admissible candidate / cheapest of all
         int bestAxis = -1, bestBin = -1;
         for (int axis = 0; axis < 3; ++axis) {
             float ext = cb.hi[axis] - cb.lo[axis];
@@ -132,9 +134,10 @@ struct Builder {
                 c += cnt[k];
                 uint32_t nl = c, nr = rightCnt[k + 1];
                 if (nl == 0 || nr == 0) continue;
+                float cost = acc.half_area() * (float)nl + rightArea[k + 1] * (float)nr;
+                freeCost = std::min(freeCost, cost);
                 // both sides must still fit under the height bound
                 if (level + min_levels(nl) > kMaxTreeHeight || level + min_levels(nr) > kMaxTreeHeight) continue;
-                float cost = acc.half_area() * (float)nl + rightArea[k + 1] * (float)nr;
                 if (cost < bestCost) {
                     bestCost = cost;
                     bestAxis = axis;
@@ -143,6 +146,7 @@ struct Builder {
             }
         }
 
+        if (freeCost < bestCost) capped.fetch_add(1, std::memory_order_relaxed);
         if (bestAxis >= 0) {
             const float lo = cb.lo[bestAxis];
             const float scale = (float)kBins / (cb.hi[bestAxis] - lo);
@@ -283,6 +287,7 @@ void build_tree(const float *verts, const uint32_t *which, uint32_t n, FlatTree 
 
     out.nnodes = nnodes;
     out.height = height;
+    out.capped_splits = B.capped.load();
     out.order.resize(n);
     for (uint32_t k = 0; k < n; ++k) out.order[k] = B.prims[k].id;
 
@@ -360,7 +365,10 @@ void triangle_record(const rt_scene_desc &desc, uint32_t id, float *q) {
 void build_flat_scene(const rt_scene_desc &desc, FlatScene &out) {
     auto t0 = std::chrono::steady_clock::now();
     const uint32_t n = desc.ntri;
-    if (n >= kMaxTriangles) throw std::runtime_error("too many triangles (limit 2^28 - 1)");
+    if (n > kMaxTriangles)
+        throw std::runtime_error("too many triangles (limit " + std::to_string(kMaxTriangles) + " = " +
+                                 std::to_string(kMaxLeafTris) + " per leaf under " + std::to_string(kMaxTreeHeight) +
+                                 " inner levels, the kernels' traversal stack)");
     if (n && (!desc.tri_verts || !desc.tri_material)) throw std::runtime_error("null triangle arrays");
     if (desc.nmat && !desc.materials) throw std::runtime_error("null material table");
     for (uint32_t i = 0; i < n; ++i)
@@ -373,6 +381,7 @@ void build_flat_scene(const rt_scene_desc &desc, FlatScene &out) {
     out.nnodes = tree.nnodes;
     out.ntri = n;
     out.tree_height = tree.height;
+    out.capped_splits = tree.capped_splits;
     out.nodes.swap(tree.nodes);
     for (int a = 0; a < 3; ++a) {
         out.grid_origin[a] = tree.grid_origin[a];

@@ -77,33 +77,51 @@ hipError_t dev_alloc(rt_scene *s, T **p, size_t count) {
     return e;
 }
 
+template <typename T>
+void dev_free(rt_scene *s, T *&p, size_t count) {
+    if (!p) return;
+    (void)hipFree(p);
+    p = nullptr;
+    s->device_bytes -= (count ? count : 1) * sizeof(T);
+}
+
 void free_wavefront(rt_scene *s) {
     rt::WavefrontBuffers &w = s->wf;
-    (void)hipFree(w.ray);
-    (void)hipFree(w.state);
-    (void)hipFree(w.queue[0]);
-    (void)hipFree(w.queue[1]);
-    (void)hipFree(w.qcount);
-    (void)hipFree(w.cursors);
+    const size_t cap = w.capacity;
+    dev_free(s, w.ray, cap * 2);
+    dev_free(s, w.state, cap * 2);
+    dev_free(s, w.queue[0], cap);
+    dev_free(s, w.queue[1], cap);
+    dev_free(s, w.qcount, (size_t)4);
+    dev_free(s, w.cursors, rt::kWfCursorWords);
     w = rt::WavefrontBuffers();
 }
 
 // Path records in flight per wavefront pass: whole frames of samples, up to 64 of them or about 128M
-// paths (72 B each with the queues: 9.7 GB of the 288 GB).  The deeper bounces of a pass keep only a
-// few percent of its paths alive, and every launch pays a ramp and a drain of about one ray's
-// duration, so fewer, larger launches win: 16M -> 3424, 32M -> 3656, 64M -> 3763, 128M -> 3827 Mrays/s
-// on the million-triangle 1080p depth-8 workload (4M: 1588 before the other optimisations).
-// RT_WF_PATHS overrides.
-int ensure_wavefront(rt_scene *s, uint32_t npix) {
+// paths (72 B each with the queues: 9.7 GB of the 288 GB), never more than the call renders.  The
+// deeper bounces of a pass keep only a few percent of its paths alive, and every launch pays a ramp
+// and a drain of about one ray's duration, so fewer, larger launches win: 16M -> 3424, 32M -> 3656,
+// 64M -> 3763, 128M -> 3827 Mrays/s on the million-triangle 1080p depth-8 workload (4M: 1588 before
+// the other optimisations).  RT_WF_PATHS overrides the path budget.
+uint32_t wavefront_slots(uint32_t npix, uint32_t spp_count) {
     uint64_t target = 128u << 20;
     if (const char *e = std::getenv("RT_WF_PATHS")) target = std::strtoull(e, nullptr, 0);
     uint64_t slots = target / npix;
-    if (slots < 1) slots = 1;
     if (slots > 64) slots = 64;
-    const uint64_t cap64 = slots * npix;
+    if (slots > spp_count) slots = spp_count;
+    if (slots < 1) slots = 1;
+    return (uint32_t)slots;
+}
+
+// Makes the scene's path-record buffers hold at least `slots` frames of npix paths.  The buffers only
+// ever grow: a smaller request keeps what is there.  Growing waits for the device (the old buffers may
+// still be in use by enqueued launches) and allocates.
+int ensure_wavefront(rt_scene *s, uint32_t npix, uint32_t slots) {
+    const uint64_t cap64 = (uint64_t)slots * npix;
     if (cap64 > 0x7FFFFFFFull) return fail(RT_ERR_LIMIT, "wavefront pipeline: image too large");
     const uint32_t cap = (uint32_t)cap64;
-    if (s->wf.capacity == cap) return RT_OK;
+    if (s->wf.capacity >= cap) return RT_OK;
+    RT_HIP(hipDeviceSynchronize());
     free_wavefront(s);
     rt::WavefrontBuffers &w = s->wf;
     RT_HIP(dev_alloc(s, &w.ray, (size_t)cap * 2));
@@ -115,6 +133,17 @@ int ensure_wavefront(rt_scene *s, uint32_t npix) {
     RT_HIP(dev_alloc(s, &w.cursors, rt::kWfCursorWords));
     RT_HIP(hipMemset(w.cursors, 0, rt::kWfCursorWords * sizeof(uint32_t)));
     w.capacity = cap;
+    return RT_OK;
+}
+
+int ensure_replay(rt_scene *s, const rt::RenderParams &rp) {
+    const uint64_t words = rt::replay_words(rp);
+    if (words <= s->replay_words) return RT_OK;
+    RT_HIP(hipDeviceSynchronize());
+    dev_free(s, s->d_replay, (size_t)s->replay_words);
+    s->replay_words = 0;
+    RT_HIP(dev_alloc(s, &s->d_replay, (size_t)words));
+    s->replay_words = words;
     return RT_OK;
 }
 
@@ -242,7 +271,7 @@ void rt_scene_destroy(rt_scene *s) {
     if (!s) return;
     DeviceGuard g(s->device);
     free_wavefront(s);
-    (void)hipFree(s->d_replay);
+    dev_free(s, s->d_replay, (size_t)s->replay_words);
     s->timer.release();
     (void)hipFree(s->d_nodes);
     (void)hipFree(s->d_tris);
@@ -262,6 +291,8 @@ int rt_scene_get_stats(const rt_scene *s, rt_scene_stats *out) {
     out->tree_height = s->flat.tree_height;
     out->build_seconds = s->flat.build_seconds;
     out->device_bytes = s->device_bytes;
+    out->height_capped_splits = s->flat.capped_splits;
+    out->reserved_ = 0;
     return RT_OK;
 }
 
@@ -365,25 +396,33 @@ int rt_render_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_beg
     if (pipeline == RT_PIPE_MEGAKERNEL && rng_mode == RT_RNG_REFERENCE) {
         // the reference's stream in the reference's evaluation order (bit-exact validation path)
         if (max_depth > 64) return fail(RT_ERR_LIMIT, "rt_render_dev: RT_RNG_REFERENCE supports max_depth <= 64");
-        const uint64_t words = rt::replay_words(rp);
-        if (words > s->replay_words) {
-            RT_HIP(hipDeviceSynchronize());
-            (void)hipFree(s->d_replay);
-            s->d_replay = nullptr;
-            s->device_bytes -= s->replay_words * 4;
-            s->replay_words = 0;
-            RT_HIP(dev_alloc(s, &s->d_replay, (size_t)words));
-            s->replay_words = words;
-        }
+        rc = ensure_replay(s, rp);
+        if (rc != RT_OK) return rc;
         RT_HIP(rt::launch_render_replay(s->view, rp, d_radiance_sum, s->d_replay, s->counting, (hipStream_t)stream, s->timer));
     } else if (pipeline == RT_PIPE_MEGAKERNEL) {
         RT_HIP(rt::launch_render_mega(s->view, rp, d_radiance_sum, s->counting, (hipStream_t)stream, s->timer));
     } else {
-        rc = ensure_wavefront(s, width * height);
+        const uint32_t slots = wavefront_slots(width * height, spp_count);
+        rc = ensure_wavefront(s, width * height, slots);
         if (rc != RT_OK) return rc;
-        RT_HIP(rt::launch_render_wavefront(s->view, rp, d_radiance_sum, s->wf, s->counting, (hipStream_t)stream, s->timer));
+        RT_HIP(rt::launch_render_wavefront(s->view, rp, d_radiance_sum, s->wf, slots, s->counting, (hipStream_t)stream, s->timer));
     }
     return RT_OK;
+}
+
+int rt_scene_reserve(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_count, uint32_t max_depth, int rng_mode,
+                     int pipeline) {
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_reserve: null scene");
+    int rc = check_image(width, height);
+    if (rc != RT_OK) return rc;
+    DeviceGuard g(s->device);
+    if (pipeline == RT_PIPE_WAVEFRONT) return ensure_wavefront(s, width * height, wavefront_slots(width * height, spp_count));
+    if (pipeline == RT_PIPE_MEGAKERNEL && rng_mode == RT_RNG_REFERENCE) {
+        if (max_depth > 64) return fail(RT_ERR_LIMIT, "rt_scene_reserve: RT_RNG_REFERENCE supports max_depth <= 64");
+        rt::RenderParams rp{width, height, 0u, spp_count, max_depth, rng_mode, 0u};
+        return ensure_replay(s, rp);
+    }
+    return RT_OK;  // the counter-RNG megakernel needs no scratch
 }
 
 int rt_render(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth,
@@ -446,6 +485,37 @@ int rt_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_
     f.write(reinterpret_cast<const char *>(rgb), (std::streamsize)((size_t)width * height * 3));
     f.close();
     if (!f) return fail(RT_ERR_IO, std::string("rt_write_ppm: write failed for ") + path);
+    return RT_OK;
+}
+
+int rt_selftest_rng(int device, const uint32_t *seeds, uint32_t nseeds, uint32_t n, uint32_t nlights, int what, float *uni,
+                    float *nrm, uint32_t *ui) {
+    if (!seeds || !uni || !nrm || !ui) return fail(RT_ERR_INVALID, "rt_selftest_rng: null argument");
+    if (what < 0 || what > 4) return fail(RT_ERR_INVALID, "rt_selftest_rng: what must be 0..4");
+    if (nlights == 0 || nlights > 65536u) return fail(RT_ERR_INVALID, "rt_selftest_rng: nlights must be in 1..65536");
+    if ((uint64_t)nseeds * n > (1ull << 26)) return fail(RT_ERR_LIMIT, "rt_selftest_rng: more than 2^26 values");
+    if (device < 0 || device >= rt_device_count()) return fail(RT_ERR_INVALID, "rt_selftest_rng: device index out of range");
+    DeviceGuard g(device);
+    const size_t total = (size_t)nseeds * n;
+    if (total == 0) return RT_OK;
+    uint32_t *d_seeds = nullptr, *d_ui = nullptr;
+    float *d_uni = nullptr, *d_nrm = nullptr;
+    hipError_t e = hipSuccess;
+    if ((e = hipMalloc((void **)&d_seeds, (size_t)nseeds * 4)) == hipSuccess &&
+        (e = hipMalloc((void **)&d_uni, total * 4)) == hipSuccess && (e = hipMalloc((void **)&d_nrm, total * 4)) == hipSuccess &&
+        (e = hipMalloc((void **)&d_ui, total * 4)) == hipSuccess &&
+        (e = hipMemcpy(d_seeds, seeds, (size_t)nseeds * 4, hipMemcpyHostToDevice)) == hipSuccess &&
+        (e = hipMemset(d_uni, 0, total * 4)) == hipSuccess && (e = hipMemset(d_nrm, 0, total * 4)) == hipSuccess &&
+        (e = hipMemset(d_ui, 0, total * 4)) == hipSuccess &&
+        (e = rt::launch_rng_selftest(d_seeds, nseeds, n, nlights, what, d_uni, d_nrm, d_ui, nullptr)) == hipSuccess &&
+        (e = hipDeviceSynchronize()) == hipSuccess && (e = hipMemcpy(uni, d_uni, total * 4, hipMemcpyDeviceToHost)) == hipSuccess &&
+        (e = hipMemcpy(nrm, d_nrm, total * 4, hipMemcpyDeviceToHost)) == hipSuccess)
+        e = hipMemcpy(ui, d_ui, total * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_seeds);
+    (void)hipFree(d_uni);
+    (void)hipFree(d_nrm);
+    (void)hipFree(d_ui);
+    if (e != hipSuccess) return hip_fail("rt_selftest_rng", e);
     return RT_OK;
 }
 

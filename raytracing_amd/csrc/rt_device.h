@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "rt_libm.h"
+
 namespace rtd {
 
 constexpr float kEps = 0.0001f;    // EPS, main.cpp:22
@@ -71,40 +73,9 @@ __device__ __forceinline__ uint32_t rng_uint(uint32_t &x, uint32_t L) {
     return r / scaling;
 }
 
-// Natural logarithm of a normal float for the polar method below.  The reference calls
-// std::log(float) = glibc's logf, whose published algorithm (a 16-entry table of 1/c and log c, a
-// degree-3 polynomial, all in double, one final rounding to float) is restated here so that the
-// Gaussian samples -- and with them every later branch of a path -- come out bit-identical to the
-// CPU's.  Checked on the host against libm's logf for all 1 056 964 609 normal floats in (0, 1]
-// (glibc 2.35, with and without fused multiply-adds): no mismatch.
-__device__ const double kLogfTab[16][2] = {
-    {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
-    {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},  {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
-    {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
-    {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
-    {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1p+0, 0x0p+0},
-    {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
-    {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},
-    {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2},
-};
-__device__ __forceinline__ float rng_logf(float v) {
-    const uint32_t ix = __float_as_uint(v);
-    if (ix == 0x3f800000u) return 0.f;
-    const uint32_t tmp = ix - 0x3f330000u;
-    const int i = (int)((tmp >> 19) & 15u);
-    const int k = (int)tmp >> 23;  // arithmetic shift
-    const uint32_t iz = ix - (tmp & (0x1ffu << 23));
-    const double invc = kLogfTab[i][0], logc = kLogfTab[i][1];
-    const double z = (double)__uint_as_float(iz);
-    const double r = z * invc - 1.0;
-    const double y0 = logc + (double)k * 0x1.62e42fefa39efp-1;
-    const double r2 = r * r;
-    double y = 0x1.5575b0be00b6ap-2 * r + -0x1.ffffef20a4123p-2;
-    y = -0x1.00ea348b88334p-2 * r2 + y;
-    y = y * r2 + (y0 + r);
-    return (float)y;
-}
-
+// The polar method below takes std::log of a float = glibc's logf; rt_logf (rt_libm.h) restates that
+// algorithm so that the Gaussian samples -- and with them every later branch of a path -- come out
+// bit-identical to the CPU's.
 // normal_distribution<float>(0,1), Marsaglia polar; the distribution object is a temporary in
 // the reference, so its cached second variate is discarded and every call runs the loop and
 // returns y * mult.
@@ -115,7 +86,7 @@ __device__ __forceinline__ float rng_normal(uint32_t &x) {
         b = 2.0f * rng_uniform(x) - 1.0f;
         r2 = a * a + b * b;
     } while (r2 > 1.0f || r2 == 0.0f);
-    const float mult = __builtin_sqrtf(-2.f * rng_logf(r2) / r2);
+    const float mult = __builtin_sqrtf(-2.f * rt_logf(r2) / r2);
     return b * mult;
 }
 
@@ -798,10 +769,8 @@ __device__ __forceinline__ float tonemap_channel(float sum, float spp) {
     const float x = sum / spp;
     float r = (x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f);
     r = __builtin_fminf(__builtin_fmaxf(r, 0.f), 1.f);
-    // glm::pow -> powf.  Evaluated in double and rounded once: libm's powf is itself a double-precision
-    // kernel rounded to float, so the two agree except where a result sits within ~1e-10 relative of a
-    // rounding boundary (the device's single-precision powf differs in the last bit far more often).
-    return (float)::pow((double)r, (double)(1.f / 2.2f));
+    // glm::pow -> powf: glibc's kernel restated (rt_libm.h), bit-identical to libm on [0, 1]
+    return rt_powf(r, 1.f / 2.2f);
 }
 
 }  // namespace rtd

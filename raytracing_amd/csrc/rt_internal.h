@@ -20,8 +20,10 @@ namespace rt {
 // Traversal limits the kernels are built for; checked on the host before any launch.
 constexpr uint32_t kMaxLeafTris = 2;     // reference: 4 (main.cpp:618); a lane slot of the triangle phase costs ~2.3 node slots, and 2 measured +2 %
 constexpr uint32_t kStackEntries = 24;   // per-lane traversal stack held in LDS
-constexpr uint32_t kMaxTreeHeight = 24;  // builder guarantee: pending stack entries <= height
-constexpr uint32_t kMaxTriangles = 1u << 28;
+constexpr uint32_t kMaxTreeHeight = RT_MAX_TREE_HEIGHT;  // builder guarantee: pending stack entries <= height
+constexpr uint32_t kMaxTriangles = RT_MAX_TRIANGLES;     // kMaxLeafTris leaves under kMaxTreeHeight inner levels
+static_assert(kMaxTriangles == kMaxLeafTris << kMaxTreeHeight, "triangle limit follows from leaf size and height");
+static_assert(kStackEntries >= kMaxTreeHeight, "the traversal stack must cover the tree height");
 
 // Flattened acceleration structure, exactly as it lies in HBM.
 //
@@ -51,6 +53,7 @@ struct FlatTree {
     float grid_cell[3] = {1.f, 1.f, 1.f};
     uint32_t nnodes = 0;
     uint32_t height = 0;
+    uint32_t capped_splits = 0;  // splits where the height bound overrode the cheapest SAH candidate
 };
 
 struct FlatScene {
@@ -70,6 +73,7 @@ struct FlatScene {
     uint32_t nnodes = 0;
     uint32_t ntri = 0;
     uint32_t tree_height = 0;
+    uint32_t capped_splits = 0;
     double build_seconds = 0.0;
 };
 

@@ -435,6 +435,24 @@ __global__ __launch_bounds__(kBlock) void k_tonemap(const float *__restrict__ su
     }
 }
 
+// Self-test of the RNG restatements: thread k seeds an engine with seeds[k] (as generatePixel does,
+// main.cpp:1221) and writes n values per output array at [k * n + i].  what 0: per i one uniform, one
+// normal, one uint in [0, L) in that order from ONE engine (the interleaving a path produces);
+// 1 / 2 / 3: only uniforms / normals / uints; 4: raw engine outputs (into ui).
+__global__ void k_rng_selftest(const uint32_t *__restrict__ seeds, uint32_t nseeds, uint32_t n, uint32_t L, int what,
+                               float *__restrict__ uni, float *__restrict__ nrm, uint32_t *__restrict__ ui) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nseeds) return;
+    uint32_t x = rng_seed(seeds[k]);
+    for (uint32_t i = 0; i < n; ++i) {
+        const size_t o = (size_t)k * n + i;
+        if (what == 0 || what == 1) uni[o] = rng_uniform(x);
+        if (what == 0 || what == 2) nrm[o] = rng_normal(x);
+        if (what == 0 || what == 3) ui[o] = rng_uint(x, L);
+        if (what == 4) ui[o] = rng_next(x);
+    }
+}
+
 inline uint32_t pixel_grid(uint32_t W, uint32_t H) { return ((W + 15u) / 16u) * ((H + 15u) / 16u); }
 inline uint32_t ceil_blocks(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 constexpr uint32_t kPersistentBlocks = 256u * 8u;  // 256 CUs x 8 workgroups for grid-stride kernels
@@ -493,9 +511,12 @@ hipError_t launch_render_replay(const DevScene &S, const RenderParams &rp, float
 }
 
 hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, float *radiance_sum,
-                                   const WavefrontBuffers &wb, bool count, hipStream_t stream, KernelTimer &timer) {
+                                   const WavefrontBuffers &wb, uint32_t slots, bool count, hipStream_t stream,
+                                   KernelTimer &timer) {
     const uint32_t npix = rp.W * rp.H;
-    const uint32_t slots = wb.capacity / npix;  // samples in flight per pass (host guarantees >= 1)
+    // `slots` = whole frames of samples in flight per pass; the host guarantees 1 <= slots and
+    // slots * npix <= wb.capacity.  A pixel's samples are added in sample order whatever the pass
+    // boundaries are (wf_accumulate continues from the stored sum), so the result does not depend on slots.
     WfView V{wb.ray, wb.state, wb.capacity};
     uint32_t done = 0;
     bool first = true;
@@ -538,6 +559,14 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
         if (e != hipSuccess) return e;
     }
     if (rp.spp_count == 0) return hipMemsetAsync(radiance_sum, 0, (size_t)npix * 3 * sizeof(float), stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_rng_selftest(const uint32_t *seeds, uint32_t nseeds, uint32_t n, uint32_t L, int what, float *uni,
+                               float *nrm, uint32_t *ui, hipStream_t stream) {
+    if (nseeds == 0 || n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rng_selftest, dim3((nseeds + 63u) / 64u), dim3(64), 0, stream, seeds, nseeds, n, L, what, uni, nrm,
+                       ui);
     return hipGetLastError();
 }
 

@@ -105,7 +105,10 @@ uint64_t replay_words(const RenderParams &rp);
 hipError_t launch_render_replay(const rtd::DevScene &S, const RenderParams &rp, float *radiance_sum, uint32_t *rec,
                                 bool count, hipStream_t stream, KernelTimer &timer);
 hipError_t launch_render_wavefront(const rtd::DevScene &S, const RenderParams &rp, float *radiance_sum,
-                                   const WavefrontBuffers &wb, bool count, hipStream_t stream, KernelTimer &timer);
+                                   const WavefrontBuffers &wb, uint32_t slots, bool count, hipStream_t stream,
+                                   KernelTimer &timer);
+hipError_t launch_rng_selftest(const uint32_t *seeds, uint32_t nseeds, uint32_t n, uint32_t L, int what, float *uni,
+                               float *nrm, uint32_t *ui, hipStream_t stream);
 hipError_t launch_tonemap(const float *radiance_sum, uint64_t npixels, uint32_t spp, float *out_float,
                           uint8_t *out_rgb, hipStream_t stream, KernelTimer &timer);
 
