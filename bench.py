@@ -4,10 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--pipeline mega|wavefront]
 
 Workload (default `spheres1m`): the million-triangle mixed-material scene at 1920x1080, path depth 8,
-counter RNG, 128 samples per pixel PER GPU (8 GPUs = the 1024-spp frame BASELINE.json's metric is
-quoted on; weak scaling).  One step = every rank renders its sample range of the whole frame into its
-radiance-sum buffer, the buffers are summed onto rank 0 (RCCL reduce; nothing for N=1) and rank 0 tone-maps
-the frame.  The scene is resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+counter RNG, 1024 samples per pixel IN TOTAL -- the frame BASELINE.json's metric is quoted on -- split
+evenly over the GPUs (strong scaling: 1024 on one GPU, 128 each on eight).  One step = one whole frame:
+every rank renders its sample range of every pixel into its radiance-sum buffer, the buffers are summed
+onto rank 0 (RCCL reduce; nothing for N=1) and rank 0 tone-maps the frame.  The scene is resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line.
 
 For N>1 launch with torch.distributed.run (one process per GPU); RANK/LOCAL_RANK/WORLD_SIZE come from
 the environment.
@@ -26,8 +27,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 WORKLOADS = {
-    # name: (scene generator name, generator kwargs, W, H, spp per GPU, depth)
-    "spheres1m": ("spheres1m", {}, 1920, 1080, 128, 8),
+    # name: (scene generator name, generator kwargs, W, H, spp of the whole frame, depth)
+    "spheres1m": ("spheres1m", {}, 1920, 1080, 1024, 8),
     "cornell": ("cornell", {}, 1920, 1080, 256, 8),
     "glass4k": ("glass", {"grid": 6, "subdiv": 5}, 3840, 2160, 64, 16),
     "emissive": ("emissive", {"subdiv": 4, "lamps": 3}, 1920, 1080, 16, 8),   # 15 360 light triangles
@@ -41,7 +42,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="spheres1m", choices=sorted(WORKLOADS))
     ap.add_argument("--pipeline", default="wavefront", choices=["mega", "wavefront"])
-    ap.add_argument("--spp-per-gpu", type=int, default=0, help="override the workload's samples per pixel per GPU")
+    ap.add_argument("--spp", type=int, default=0, help="override the workload's samples per pixel of the whole frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-primary", action="store_true")
     args = ap.parse_args()
@@ -74,9 +75,12 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
 
-    gen, gen_kw, W, H, spp_gpu, depth = WORKLOADS[args.workload]
-    if args.spp_per_gpu > 0:
-        spp_gpu = args.spp_per_gpu
+    gen, gen_kw, W, H, spp_total, depth = WORKLOADS[args.workload]
+    if args.spp > 0:
+        spp_total = args.spp
+    if spp_total % world:
+        raise SystemExit("the frame's %d samples per pixel do not divide over %d GPUs" % (spp_total, world))
+    spp_gpu = spp_total // world
     pipeline = rt.PIPE_MEGAKERNEL if args.pipeline == "mega" else rt.PIPE_WAVEFRONT
     seed = 0x5EED
     npix = W * H
@@ -86,6 +90,7 @@ def main():
     host = rt.load_gltf(path, W, H)
     scene = rt.Scene(host, device=local_rank)
     stats = scene.stats()
+    scene.reserve(W, H, spp_gpu, max_depth=depth, rng_mode=rt.RNG_COUNTER, pipeline=pipeline)  # render_dev only enqueues
 
     stream = torch.cuda.current_stream()
     buf = torch.empty(npix * 3, dtype=torch.float32, device=dev)
@@ -97,7 +102,7 @@ def main():
         if use_dist:
             dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM)
         if rank == 0:
-            scene.tonemap_dev(buf.data_ptr(), npix, spp_gpu * world, out_rgb_ptr=rgb.data_ptr(), stream=stream)
+            scene.tonemap_dev(buf.data_ptr(), npix, spp_total, out_rgb_ptr=rgb.data_ptr(), stream=stream)
 
     def barrier():
         if use_dist:
@@ -225,12 +230,13 @@ def main():
     out = {
         "metric": "Mrays/s (all bounces)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d triangles, %dx%d, %d spp per GPU (%d total), depth %d, counter RNG, %s pipeline"
-                               % (args.workload, stats["ntri"], W, H, spp_gpu, spp_gpu * world, depth, args.pipeline),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %d triangles, %dx%d, %d spp per frame (%d per GPU), depth %d, counter RNG, %s pipeline"
+                               % (args.workload, stats["ntri"], W, H, spp_total, spp_gpu, depth, args.pipeline),
                    "parallelism": "spp-split x%d + RCCL reduce" % world if world > 1 else "single GPU",
                    "ms_per_frame": round(elapsed / args.steps * 1e3, 3),
                    "bvh": {"nodes": stats["nnodes"], "height": stats["tree_height"],
+                           "height_capped_splits": stats["height_capped_splits"],
                            "build_s": round(stats["build_seconds"], 3)}},
         "roofline": roofline, "cpu_baseline": cpu,
     }

@@ -191,6 +191,10 @@ int rt_flat_get(const rt_flat *f, uint32_t info[4], float grid[6], uint32_t *nod
  * record (16 floats) per light in this tree's leaf order, word 12 = index in the light list,
  * word 13 = the light's leaf position in the main triangle array.  Any pointer may be NULL. */
 int rt_flat_get_light_tree(const rt_flat *f, uint32_t info[2], float grid[6], uint32_t *nodes, float *recs);
+/* Quality of the main tree: the rt_scene_stats counter of splits the height bound overrode, and the
+ * surface-area estimate of the work per random ray through the scene's bounds (expected node visits,
+ * expected ray/triangle tests).  Any pointer may be NULL. */
+int rt_flat_get_quality(const rt_flat *f, uint32_t *height_capped_splits, double *sah_nodes, double *sah_tris);
 void rt_flat_free(rt_flat *f);
 
 /* ---- closest hit: stands in for intersectScene / BVH::intersect, main.cpp:1113, 560-605 ---- */

@@ -118,9 +118,12 @@ def build_flat(host_scene):
         lnodes = np.empty((int(linfo[0]), 8), dtype=np.uint32)
         lrecs = np.empty((lights.size, 16), dtype=np.float32)
         check(L.rt_flat_get_light_tree(h, None, _p(lgrid), _p(lnodes), _p(lrecs) if lights.size else None))
+        capped, sah_n, sah_t = C.c_uint32(), C.c_double(), C.c_double()
+        check(L.rt_flat_get_quality(h, C.byref(capped), C.byref(sah_n), C.byref(sah_t)))
     finally:
         L.rt_flat_free(h)
     return dict(nodes=nodes, grid=grid, tris=tris, lights=lights, height=int(info[3]),
+                height_capped_splits=int(capped.value), sah_nodes=float(sah_n.value), sah_tris=float(sah_t.value),
                 light_tree=dict(nodes=lnodes, grid=lgrid, recs=lrecs, height=int(linfo[1])))
 
 

@@ -288,6 +288,26 @@ void build_tree(const float *verts, const uint32_t *which, uint32_t n, FlatTree 
     out.nnodes = nnodes;
     out.height = height;
     out.capped_splits = B.capped.load();
+    {   // surface-area estimate of the work per random ray: a child is entered with probability
+        // area(child box) / area(root box); an inner child costs a node visit, a leaf its triangle tests
+        Box rootBox;
+        rootBox.reset();
+        rootBox.grow(B.nodes[root].box[0]);
+        if (B.nodes[root].box[1].lo[0] < 1.0e30f) rootBox.grow(B.nodes[root].box[1]);
+        const double ra = std::max((double)rootBox.half_area(), 1e-30);
+        double en = 1.0, et = 0.0;
+        for (uint32_t k = 0; k < nnodes; ++k)
+            for (int c = 0; c < 2; ++c) {
+                const Box &b = B.nodes[k].box[c];
+                if (!(b.lo[0] < 1.0e30f)) continue;
+                const double p = (double)b.half_area() / ra;
+                const int32_t ref = B.nodes[k].child[c];
+                if (ref >= 0) en += p;
+                else et += p * (double)(((uint32_t)~ref & 7u) + 1u);
+            }
+        out.sah_nodes = n ? en : 0.0;
+        out.sah_tris = n ? et : 0.0;
+    }
     out.order.resize(n);
     for (uint32_t k = 0; k < n; ++k) out.order[k] = B.prims[k].id;
 
@@ -382,6 +402,8 @@ void build_flat_scene(const rt_scene_desc &desc, FlatScene &out) {
     out.ntri = n;
     out.tree_height = tree.height;
     out.capped_splits = tree.capped_splits;
+    out.sah_nodes = tree.sah_nodes;
+    out.sah_tris = tree.sah_tris;
     out.nodes.swap(tree.nodes);
     for (int a = 0; a < 3; ++a) {
         out.grid_origin[a] = tree.grid_origin[a];
@@ -507,6 +529,17 @@ int rt_flat_get_light_tree(const rt_flat *f, uint32_t info[2], float grid[6], ui
         }
     if (nodes) std::memcpy(nodes, s.light_nodes.data(), (size_t)s.light_nnodes * 8 * sizeof(uint32_t));
     if (recs) std::memcpy(recs, s.light_recs.data(), s.lights.size() * 16 * sizeof(float));
+    return RT_OK;
+}
+
+int rt_flat_get_quality(const rt_flat *f, uint32_t *height_capped_splits, double *sah_nodes, double *sah_tris) {
+    if (!f) {
+        rt::set_error("rt_flat_get_quality: null argument");
+        return RT_ERR_INVALID;
+    }
+    if (height_capped_splits) *height_capped_splits = f->flat.capped_splits;
+    if (sah_nodes) *sah_nodes = f->flat.sah_nodes;
+    if (sah_tris) *sah_tris = f->flat.sah_tris;
     return RT_OK;
 }
 

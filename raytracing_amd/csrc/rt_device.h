@@ -768,7 +768,9 @@ __device__ __forceinline__ v3 fold_backward(const DevScene &S, const LightCache 
 __device__ __forceinline__ float tonemap_channel(float sum, float spp) {
     const float x = sum / spp;
     float r = (x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f);
-    r = __builtin_fminf(__builtin_fmaxf(r, 0.f), 1.f);
+    r = (r < 0.f) ? 0.f : r;  // glm::clamp = min(max(x, 0), 1) with glm's comparison forms: a NaN stays a NaN
+    r = (1.f < r) ? 1.f : r;
+    if (r != r) return r;     // powf(NaN, y) = NaN (an overflowed radiance sum: inf / inf in the tone curve)
     // glm::pow -> powf: glibc's kernel restated (rt_libm.h), bit-identical to libm on [0, 1]
     return rt_powf(r, 1.f / 2.2f);
 }

@@ -54,6 +54,7 @@ struct FlatTree {
     uint32_t nnodes = 0;
     uint32_t height = 0;
     uint32_t capped_splits = 0;  // splits where the height bound overrode the cheapest SAH candidate
+    double sah_nodes = 0.0, sah_tris = 0.0;  // surface-area estimate of node visits / triangle tests per random ray
 };
 
 struct FlatScene {
@@ -74,6 +75,7 @@ struct FlatScene {
     uint32_t ntri = 0;
     uint32_t tree_height = 0;
     uint32_t capped_splits = 0;
+    double sah_nodes = 0.0, sah_tris = 0.0;
     double build_seconds = 0.0;
 };
 
