@@ -229,6 +229,19 @@ int rt_render_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_beg
 int rt_scene_reserve(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_count, uint32_t max_depth,
                      int rng_mode, int pipeline);
 
+/* The wavefront render for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.
+ * Same estimator, kernels and results as rt_render_dev(..., RT_RNG_COUNTER, seed, RT_PIPE_WAVEFRONT, ...)
+ * (bit-identical sums), but the path records, queues and cursors live in a fixed array inside the
+ * library's code object (151 MB per GPU, held from the library's first launch on that GPU until the
+ * process ends) instead of scene-owned allocations, and the call makes no hipMalloc / hipFree.
+ * Limit: width * height <= RT_NOALLOC_MAX_PIXELS (one 1920x1080 frame fits), RT_ERR_LIMIT beyond;
+ * smaller images keep up to 64 frames of samples in flight.  Every call on a GPU shares that GPU's
+ * array, whatever the scene: calls that overlap on one GPU (two streams, two threads) race. */
+#define RT_NOALLOC_MAX_PIXELS (1u << 21)
+int rt_render_noalloc_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_begin, uint32_t spp_count,
+                          uint32_t max_depth, uint32_t seed, float *d_radiance_sum, void *stream);
+
 /* ---- image: mean, ACES, gamma (main.cpp:1226-1231, 827-838), truncating byte conversion
  * (colorFloatToInt, main.cpp:840-846), PPM writer (printImage, main.cpp:856-864) ---- */
 /* out_float (npixels*3, may be NULL) = SceneFloat contents; out_rgb (npixels*3, may be NULL). */

@@ -76,6 +76,8 @@ SIGNATURES = {
                             C.c_uint32, C.c_int, C.c_void_p]),
     "rt_render_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                 C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
+    "rt_render_noalloc_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                        C.c_uint32, C.c_void_p, C.c_void_p]),
     "rt_scene_reserve": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
     "rt_selftest_rng": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),

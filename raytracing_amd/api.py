@@ -234,6 +234,13 @@ class Scene:
                                        int(rng_mode), int(seed), int(pipeline), C.c_void_p(radiance_sum_ptr),
                                        _stream_ptr(stream)))
 
+    def render_noalloc_dev(self, width, height, spp, radiance_sum_ptr, max_depth=6, seed=0, spp_begin=0, stream=None):
+        """render_dev with the counter RNG and the wavefront pipeline out of the library's static scratch:
+        no device allocation in the call; width * height <= 2^21."""
+        check(_lib.lib().rt_render_noalloc_dev(self._h, int(width), int(height), int(spp_begin), int(spp),
+                                               int(max_depth), int(seed), C.c_void_p(radiance_sum_ptr),
+                                               _stream_ptr(stream)))
+
     def reserve(self, width, height, spp, max_depth=6, rng_mode=RNG_COUNTER, pipeline=PIPE_WAVEFRONT):
         """Allocate the scratch a render of this shape needs, so that render_dev only enqueues."""
         check(_lib.lib().rt_scene_reserve(self._h, int(width), int(height), int(spp), int(max_depth), int(rng_mode),

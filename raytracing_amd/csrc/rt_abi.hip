@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -39,7 +40,49 @@ struct rt_scene {
     uint64_t host_segments = 0;  // segments of launches whose ray count the host knows (one per ray)
 };
 
+// ---- static scratch of rt_render_noalloc_dev ---------------------------------------------------
+// Path records, index queues, queue counters and work cursors of the wavefront pipeline for
+// kNoAllocPaths paths in flight, laid out back to back in one array that is part of the library's code
+// object: every GPU the library runs on holds its own copy from the first launch on that GPU until the
+// process ends (151 MB).  Host code must not use the array's name as an address: the address on a
+// given GPU comes from hipGetSymbolAddress with that GPU current (scratch_of below).
 namespace {
+constexpr uint32_t kNoAllocPaths = RT_NOALLOC_MAX_PIXELS;  // one path per pixel at least
+constexpr size_t kScratchRay = 0;                                         // float4[2 * paths]
+constexpr size_t kScratchState = kScratchRay + (size_t)kNoAllocPaths * 32;    // float4[2 * paths]
+constexpr size_t kScratchQueue0 = kScratchState + (size_t)kNoAllocPaths * 32; // uint32_t[paths]
+constexpr size_t kScratchQueue1 = kScratchQueue0 + (size_t)kNoAllocPaths * 4; // uint32_t[paths]
+constexpr size_t kScratchQcount = kScratchQueue1 + (size_t)kNoAllocPaths * 4; // uint32_t[4], padded to 256 B
+constexpr size_t kScratchCursors = kScratchQcount + 256;                      // uint32_t[kWfCursorWords]
+constexpr size_t kScratchBytes = kScratchCursors + rt::kWfCursorWords * sizeof(uint32_t);
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+namespace {
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[kMaxDevices] = {nullptr};
+
+// Address of `scratch` on `device`, resolved once per device with that device current (the caller
+// holds a DeviceGuard).  Called from rt_scene_create, the per-device set-up call.
+hipError_t resolve_scratch(int device) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return hipSuccess;
+    void *p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    g_scratch_ptr[device] = static_cast<unsigned char *>(p);
+    return hipSuccess;
+}
+
+unsigned char *scratch_of(int device) {
+    if (device < 0 || device >= kMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    return g_scratch_ptr[device];
+}
 
 struct DeviceGuard {  // makes the scene's GPU current for the call, restores the caller's on exit
     int prev = -1;
@@ -194,6 +237,13 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     if (!g.ok) {
         delete s;
         return fail(RT_ERR_HIP, "rt_scene_create: hipSetDevice failed");
+    }
+    {
+        hipError_t es = resolve_scratch(device);  // the static scratch of rt_render_noalloc_dev, once per GPU
+        if (es != hipSuccess) {
+            delete s;
+            return hip_fail("rt_scene_create: hipGetSymbolAddress(scratch)", es);
+        }
     }
     const rt::FlatScene &f = s->flat;
     std::vector<rtd::DevMaterial> mats(desc->nmat ? desc->nmat : 1);
@@ -407,6 +457,44 @@ int rt_render_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_beg
         if (rc != RT_OK) return rc;
         RT_HIP(rt::launch_render_wavefront(s->view, rp, d_radiance_sum, s->wf, slots, s->counting, (hipStream_t)stream, s->timer));
     }
+    return RT_OK;
+}
+
+int rt_render_noalloc_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_begin, uint32_t spp_count,
+                          uint32_t max_depth, uint32_t seed, float *d_radiance_sum, void *stream) {
+    if (!s || !d_radiance_sum) return fail(RT_ERR_INVALID, "rt_render_noalloc_dev: null argument");
+    int rc = check_image(width, height);
+    if (rc != RT_OK) return rc;
+    const uint64_t npix64 = (uint64_t)width * height;
+    if (npix64 > kNoAllocPaths)
+        return fail(RT_ERR_LIMIT, "rt_render_noalloc_dev: image has " + std::to_string(npix64) +
+                                      " pixels, the static scratch holds path records for at most " +
+                                      std::to_string(kNoAllocPaths) + " (use rt_render_dev)");
+    if (max_depth > 65535u) return fail(RT_ERR_LIMIT, "rt_render_noalloc_dev: max_depth above 65535");
+    if ((uint64_t)spp_begin + spp_count > 0xFFFFFFFFull)
+        return fail(RT_ERR_LIMIT, "rt_render_noalloc_dev: sample range overflows 32 bits");
+    unsigned char *base = scratch_of(s->device);
+    if (!base) return fail(RT_ERR_HIP, "rt_render_noalloc_dev: the static scratch was not resolved on this device");
+    DeviceGuard g(s->device);
+    const uint32_t npix = (uint32_t)npix64;
+    uint32_t slots = kNoAllocPaths / npix;
+    if (slots > 64) slots = 64;
+    if (slots > spp_count) slots = spp_count;
+    if (slots < 1) slots = 1;
+    rt::WavefrontBuffers wb;
+    wb.capacity = kNoAllocPaths;
+    wb.ray = reinterpret_cast<float4 *>(base + kScratchRay);
+    wb.state = reinterpret_cast<float4 *>(base + kScratchState);
+    wb.queue[0] = reinterpret_cast<uint32_t *>(base + kScratchQueue0);
+    wb.queue[1] = reinterpret_cast<uint32_t *>(base + kScratchQueue1);
+    wb.qcount = reinterpret_cast<uint32_t *>(base + kScratchQcount);
+    wb.cursors = reinterpret_cast<uint32_t *>(base + kScratchCursors);
+    // the array keeps the previous call's contents: counters and cursors start from zero, the records
+    // and queues are rewritten by wf_generate / wf_shade before they are read
+    RT_HIP(hipMemsetAsync(base + kScratchQcount, 0, kScratchBytes - kScratchQcount, (hipStream_t)stream));
+    rt::RenderParams rp{width, height, spp_begin, spp_count, max_depth, RT_RNG_COUNTER, seed};
+    rt::KernelTimer untimed;  // event pairs of rt_set_timing would create events: not here
+    RT_HIP(rt::launch_render_wavefront(s->view, rp, d_radiance_sum, wb, slots, s->counting, (hipStream_t)stream, untimed));
     return RT_OK;
 }
 
