@@ -131,8 +131,7 @@ void dev_free(rt_scene *s, T *&p, size_t count) {
 void free_wavefront(rt_scene *s) {
     rt::WavefrontBuffers &w = s->wf;
     const size_t cap = w.capacity;
-    dev_free(s, w.ray, cap * 2);
-    dev_free(s, w.state, cap * 2);
+    dev_free(s, w.rec, cap * 4);
     dev_free(s, w.queue[0], cap);
     dev_free(s, w.queue[1], cap);
     dev_free(s, w.qcount, (size_t)4);
@@ -167,8 +166,9 @@ int ensure_wavefront(rt_scene *s, uint32_t npix, uint32_t slots) {
     RT_HIP(hipDeviceSynchronize());
     free_wavefront(s);
     rt::WavefrontBuffers &w = s->wf;
-    RT_HIP(dev_alloc(s, &w.ray, (size_t)cap * 2));
-    RT_HIP(dev_alloc(s, &w.state, (size_t)cap * 2));
+    RT_HIP(dev_alloc(s, &w.rec, (size_t)cap * 4));
+    w.ray = w.rec;
+    w.state = rt::kWfRecStride == 4 ? w.rec + 2 : w.rec + (size_t)cap * 2;
     RT_HIP(dev_alloc(s, &w.queue[0], (size_t)cap));
     RT_HIP(dev_alloc(s, &w.queue[1], (size_t)cap));
     RT_HIP(dev_alloc(s, &w.qcount, (size_t)4));
@@ -484,7 +484,7 @@ int rt_render_noalloc_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t
     rt::WavefrontBuffers wb;
     wb.capacity = kNoAllocPaths;
     wb.ray = reinterpret_cast<float4 *>(base + kScratchRay);
-    wb.state = reinterpret_cast<float4 *>(base + kScratchState);
+    wb.state = rt::kWfRecStride == 4 ? wb.ray + 2 : reinterpret_cast<float4 *>(base + kScratchState);
     wb.queue[0] = reinterpret_cast<uint32_t *>(base + kScratchQueue0);
     wb.queue[1] = reinterpret_cast<uint32_t *>(base + kScratchQueue1);
     wb.qcount = reinterpret_cast<uint32_t *>(base + kScratchQcount);

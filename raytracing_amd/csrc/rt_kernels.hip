@@ -213,9 +213,10 @@ constexpr uint32_t kShards = 8;           // work cursors of wf_extend (see ther
 constexpr uint32_t kCursorStride = 1024;  // words between cursors
 static_assert(kShards * kCursorStride == rt::kWfCursorWords, "cursor buffer size");
 
+constexpr size_t kRec = rt::kWfRecStride;  // float4s between consecutive records in `ray` and in `state`
 struct WfView {
-    float4 *ray;    // [2i] = (o.xyz, d.x)  [2i+1] = (d.y, d.z, hit t, bits(hit triangle))
-    float4 *state;  // [2i] = (throughput.xyz, bits(rng))  [2i+1] = (radiance.xyz, bits(depth left))
+    float4 *ray;    // [kRec i] = (o.xyz, d.x)  [kRec i + 1] = (d.y, d.z, hit t, bits(hit triangle))
+    float4 *state;  // [kRec i] = (throughput.xyz, bits(rng))  [kRec i + 1] = (radiance.xyz, bits(depth left))
     uint32_t cap;
 };
 
@@ -237,10 +238,10 @@ __global__ __launch_bounds__(kBlock) void wf_generate(DevScene S, rt::RenderPara
         const uint32_t px = pix % rp.W, py = pix / rp.W;
         uint32_t rng = rng_seed(counter_seed(pix, sample, rp.seed));
         const v3 d = primary_direction(S, px, py, rp.W, rp.H, rng);
-        V.ray[2 * (size_t)i] = make_float4(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2], d.x);
-        V.ray[2 * (size_t)i + 1] = make_float4(d.y, d.z, 0.f, 0.f);
-        V.state[2 * (size_t)i] = make_float4(1.f, 1.f, 1.f, __uint_as_float(rng));
-        V.state[2 * (size_t)i + 1] = make_float4(0.f, 0.f, 0.f, __uint_as_float(rp.max_depth));
+        V.ray[kRec * (size_t)i] = make_float4(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2], d.x);
+        V.ray[kRec * (size_t)i + 1] = make_float4(d.y, d.z, 0.f, 0.f);
+        V.state[kRec * (size_t)i] = make_float4(1.f, 1.f, 1.f, __uint_as_float(rng));
+        V.state[kRec * (size_t)i + 1] = make_float4(0.f, 0.f, 0.f, __uint_as_float(rp.max_depth));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         qcount[0] = npaths;
@@ -268,15 +269,23 @@ template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const uint32_t *__restrict__ queue,
                                                      const uint32_t *__restrict__ qcount_in,
                                                      uint32_t *__restrict__ qcount_zero, uint32_t *__restrict__ cursors) {
+#ifdef RT_NODE_DMA
+    __shared__ int s_stack[RT_NODE_DMA * kBlock];  // the host caps the tree height at RT_NODE_DMA for this build
+    __shared__ uint4 s_stage[4][128];
+    Traversal<COUNT, kExitLanes, true, true> T;
+    T.stage = s_stage[threadIdx.x >> 6];
+    T.xchg = reinterpret_cast<uint32_t *>(s_stage[threadIdx.x >> 6]);  // triangle phase only: no DMA in flight then
+#else
     __shared__ int s_stack[kStack * kBlock];
+    __shared__ uint32_t s_xchg[4][128];
+    Traversal<COUNT, kExitLanes, true> T;
+    T.xchg = s_xchg[threadIdx.x >> 6];
+#endif
     const uint32_t count = *qcount_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) *qcount_zero = 0u;  // the queue the next shade pass fills
     const uint32_t lane = threadIdx.x & 63u;
-    __shared__ uint32_t s_xchg[4][128];
-    Traversal<COUNT, kExitLanes, true> T;
     T.idle();
     T.bind(s_stack + threadIdx.x);
-    T.xchg = s_xchg[threadIdx.x >> 6];
     uint32_t slot = 0, segs = 0;
     bool hasRay = false;
     uint32_t chunkNext = 0, chunkEnd = 0;  // wave-uniform
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
     TraceStats st{0, 0, 0, 0};
     for (;;) {
         if (hasRay && T.done()) {
-            reinterpret_cast<float2 *>(V.ray + 2 * (size_t)slot + 1)[1] = make_float2(T.tBest, __int_as_float(T.triBest));
+            reinterpret_cast<float2 *>(V.ray + kRec * (size_t)slot + 1)[1] = make_float2(T.tBest, __int_as_float(T.triBest));
             hasRay = false;
             ++segs;
         }
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
                 if (!hasRay && rank >= given && rank < given + take) {
                     const uint32_t j = chunkNext + (rank - given);
                     slot = queue ? queue[j] : j;
-                    const float4 r0 = V.ray[2 * (size_t)slot], r1 = V.ray[2 * (size_t)slot + 1];
+                    const float4 r0 = V.ray[kRec * (size_t)slot], r1 = V.ray[kRec * (size_t)slot + 1];
                     T.start(S, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y));
                     hasRay = true;
                 }
@@ -368,8 +377,8 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const u
         uint32_t i = 0;
         if (j < count) {
             i = queue ? queue[j] : j;
-            const float4 r0 = V.ray[2 * (size_t)i], r1 = V.ray[2 * (size_t)i + 1];
-            const float4 s0 = V.state[2 * (size_t)i], s1 = V.state[2 * (size_t)i + 1];
+            const float4 r0 = V.ray[kRec * (size_t)i], r1 = V.ray[kRec * (size_t)i + 1];
+            const float4 s0 = V.state[kRec * (size_t)i], s1 = V.state[kRec * (size_t)i + 1];
             PathState P;
             P.o = mk(r0.x, r0.y, r0.z);
             P.d = mk(r0.w, r1.x, r1.y);
@@ -378,11 +387,11 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const u
             P.rng = __float_as_uint(s0.w);
             P.depth = __float_as_uint(s1.w);
             alive = shade_hit<TREE>(S, LC, P, r1.z, __float_as_int(r1.w), lightTests);
-            V.state[2 * (size_t)i + 1] = make_float4(P.L.x, P.L.y, P.L.z, __uint_as_float(P.depth));
+            V.state[kRec * (size_t)i + 1] = make_float4(P.L.x, P.L.y, P.L.z, __uint_as_float(P.depth));
             if (alive) {
-                V.ray[2 * (size_t)i] = make_float4(P.o.x, P.o.y, P.o.z, P.d.x);
-                V.ray[2 * (size_t)i + 1] = make_float4(P.d.y, P.d.z, 0.f, 0.f);
-                V.state[2 * (size_t)i] = make_float4(P.T.x, P.T.y, P.T.z, __uint_as_float(P.rng));
+                V.ray[kRec * (size_t)i] = make_float4(P.o.x, P.o.y, P.o.z, P.d.x);
+                V.ray[kRec * (size_t)i + 1] = make_float4(P.d.y, P.d.z, 0.f, 0.f);
+                V.state[kRec * (size_t)i] = make_float4(P.T.x, P.T.y, P.T.z, __uint_as_float(P.rng));
             }
         }
         const unsigned long long mask = __ballot(alive);
@@ -417,7 +426,7 @@ __global__ __launch_bounds__(kBlock) void wf_accumulate(WfView V, uint32_t W, ui
         v3 acc = first ? mk(0.f, 0.f, 0.f) : mk(sum[3 * (size_t)pix], sum[3 * (size_t)pix + 1], sum[3 * (size_t)pix + 2]);
         for (uint32_t s = 0; s < nslots; ++s) {
             const size_t i = (size_t)s * npix + j;
-            const float4 l = V.state[2 * i + 1];
+            const float4 l = V.state[kRec * i + 1];
             acc = acc + mk(l.x, l.y, l.z);
         }
         sum[3 * (size_t)pix] = acc.x;
@@ -456,7 +465,11 @@ __global__ void k_rng_selftest(const uint32_t *__restrict__ seeds, uint32_t nsee
 inline uint32_t pixel_grid(uint32_t W, uint32_t H) { return ((W + 15u) / 16u) * ((H + 15u) / 16u); }
 inline uint32_t ceil_blocks(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 constexpr uint32_t kPersistentBlocks = 256u * 8u;  // 256 CUs x 8 workgroups for grid-stride kernels
+#ifdef RT_NODE_DMA
+constexpr uint32_t kExtendBlocks = 256u * 5u;      // 256 CUs x 5 resident workgroups (stack + 8 KB node staging)
+#else
 constexpr uint32_t kExtendBlocks = 256u * 6u;      // 256 CUs x 6 resident workgroups (24 KB of LDS each)
+#endif
 
 }  // namespace
 

@@ -83,9 +83,18 @@ struct RenderParams {
 // quarters so that a lane moves a record with four loads or stores: the vector-memory path charges
 // per lane and instruction, not per byte), two index queues, queue counters.  Owned by the scene,
 // sized on first use.
+// Record layout: RT_REC_STRIDE 2 = two arrays (ray halves, state halves); 4 = one array of 64-byte
+// records, ray half then state half (state = ray + 2), so that a path touched through an index queue
+// costs one 64-byte sector instead of two half-used ones.
+#ifndef RT_REC_STRIDE
+#define RT_REC_STRIDE 2
+#endif
+constexpr size_t kWfRecStride = RT_REC_STRIDE;
+static_assert(kWfRecStride == 2 || kWfRecStride == 4, "record stride");
 constexpr size_t kWfCursorWords = 8 * 1024;  // 8 cursors, 4 KB apart (rt_kernels.hip: kShards x kCursorStride)
 struct WavefrontBuffers {
     uint32_t capacity = 0;
+    float4 *rec = nullptr;    // the allocation behind ray and state: 4 x capacity float4
     float4 *ray = nullptr;    // 2 x capacity: [2i] = (o.xyz, d.x)  [2i+1] = (d.y, d.z, hit t, bits(hit triangle))
     float4 *state = nullptr;  // 2 x capacity: [2i] = (throughput.xyz, bits(rng))  [2i+1] = (radiance.xyz, bits(depth left))
     uint32_t *queue[2] = {nullptr, nullptr};  // path indices alive in the current / next bounce

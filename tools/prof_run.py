@@ -54,6 +54,7 @@ def main():
     launch()
     torch.cuda.synchronize()
     scene.reset_counters(stream)
+    scene.set_timing(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.reps):
@@ -61,7 +62,8 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.reps
     c = scene.counters()
-    print("ms/launch %.3f  Mrays/s %.1f  counters %s" % (dt * 1e3, c["segments"] / a.reps / dt * 1e-6, c))
+    kt = {k: round(v[0] / a.reps, 2) for k, v in scene.kernel_times().items() if v[1]}
+    print("ms/launch %.3f  Mrays/s %.1f  kernels(ms) %s  counters %s" % (dt * 1e3, c["segments"] / a.reps / dt * 1e-6, kt, c))
 
 
 if __name__ == "__main__":

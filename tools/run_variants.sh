@@ -4,6 +4,6 @@ args=()
 while [ $# -gt 0 ] && [ "$1" != "--" ]; do args+=("$1"); shift; done
 shift
 for v in "$@"; do
-  out=$(RT_AMD_LIB=$PWD/raytracing_amd/lib/variants/$v/librt_amd.so timeout -k 10 200 python tools/prof_run.py "${args[@]}" 2>&1 | grep "ms/launch" | cut -c1-42) || exit 1
+  out=$(RT_AMD_LIB=$PWD/raytracing_amd/lib/variants/$v/librt_amd.so timeout -k 10 200 python tools/prof_run.py "${args[@]}" 2>&1 | grep "ms/launch" | cut -c1-150) || exit 1
   echo "$v: $out"
 done
