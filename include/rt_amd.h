@@ -66,11 +66,7 @@ extern "C" {
 /* Limits of the acceleration structure: leaves hold at most 2 triangles and the tree has at most
  * RT_MAX_TREE_HEIGHT inner levels (the per-lane traversal stack of the kernels), so a scene holds at
  * most 2 * 2^24 triangles; rt_scene_create / rt_flat_build return RT_ERR_LIMIT beyond that. */
-#ifdef RT_NODE_DMA
-#define RT_MAX_TREE_HEIGHT RT_NODE_DMA
-#else
 #define RT_MAX_TREE_HEIGHT 24
-#endif
 #define RT_MAX_TRIANGLES (2u << RT_MAX_TREE_HEIGHT)
 
 #define RT_MISS_ID 0xFFFFFFFFu /* prim_id of a ray that hits nothing */

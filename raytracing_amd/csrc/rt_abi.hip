@@ -48,9 +48,11 @@ struct rt_scene {
 // given GPU comes from hipGetSymbolAddress with that GPU current (scratch_of below).
 namespace {
 constexpr uint32_t kNoAllocPaths = RT_NOALLOC_MAX_PIXELS;  // one path per pixel at least
-constexpr size_t kScratchRay = 0;                                         // float4[2 * paths]
-constexpr size_t kScratchState = kScratchRay + (size_t)kNoAllocPaths * 32;    // float4[2 * paths]
-constexpr size_t kScratchQueue0 = kScratchState + (size_t)kNoAllocPaths * 32; // uint32_t[paths]
+constexpr size_t kScratchRay = 0;                                             // float4[2 * paths]
+constexpr size_t kScratchLum = kScratchRay + (size_t)kNoAllocPaths * 32;      // float4[paths]
+constexpr size_t kScratchC = kScratchLum + (size_t)kNoAllocPaths * 16;        // float2[paths]
+constexpr size_t kScratchHit = kScratchC + (size_t)kNoAllocPaths * 8;         // float2[paths]
+constexpr size_t kScratchQueue0 = kScratchHit + (size_t)kNoAllocPaths * 8;    // uint32_t[paths]
 constexpr size_t kScratchQueue1 = kScratchQueue0 + (size_t)kNoAllocPaths * 4; // uint32_t[paths]
 constexpr size_t kScratchQcount = kScratchQueue1 + (size_t)kNoAllocPaths * 4; // uint32_t[4], padded to 256 B
 constexpr size_t kScratchCursors = kScratchQcount + 256;                      // uint32_t[kWfCursorWords]
@@ -131,7 +133,10 @@ void dev_free(rt_scene *s, T *&p, size_t count) {
 void free_wavefront(rt_scene *s) {
     rt::WavefrontBuffers &w = s->wf;
     const size_t cap = w.capacity;
-    dev_free(s, w.rec, cap * 4);
+    dev_free(s, w.ray, cap * 2);
+    dev_free(s, w.c, cap);
+    dev_free(s, w.lum, cap);
+    dev_free(s, w.hit, cap);
     dev_free(s, w.queue[0], cap);
     dev_free(s, w.queue[1], cap);
     dev_free(s, w.qcount, (size_t)4);
@@ -166,9 +171,10 @@ int ensure_wavefront(rt_scene *s, uint32_t npix, uint32_t slots) {
     RT_HIP(hipDeviceSynchronize());
     free_wavefront(s);
     rt::WavefrontBuffers &w = s->wf;
-    RT_HIP(dev_alloc(s, &w.rec, (size_t)cap * 4));
-    w.ray = w.rec;
-    w.state = rt::kWfRecStride == 4 ? w.rec + 2 : w.rec + (size_t)cap * 2;
+    RT_HIP(dev_alloc(s, &w.ray, (size_t)cap * 2));
+    RT_HIP(dev_alloc(s, &w.c, (size_t)cap));
+    RT_HIP(dev_alloc(s, &w.lum, (size_t)cap));
+    RT_HIP(dev_alloc(s, &w.hit, (size_t)cap));
     RT_HIP(dev_alloc(s, &w.queue[0], (size_t)cap));
     RT_HIP(dev_alloc(s, &w.queue[1], (size_t)cap));
     RT_HIP(dev_alloc(s, &w.qcount, (size_t)4));
@@ -484,7 +490,9 @@ int rt_render_noalloc_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t
     rt::WavefrontBuffers wb;
     wb.capacity = kNoAllocPaths;
     wb.ray = reinterpret_cast<float4 *>(base + kScratchRay);
-    wb.state = rt::kWfRecStride == 4 ? wb.ray + 2 : reinterpret_cast<float4 *>(base + kScratchState);
+    wb.c = reinterpret_cast<float2 *>(base + kScratchC);
+    wb.lum = reinterpret_cast<float4 *>(base + kScratchLum);
+    wb.hit = reinterpret_cast<float2 *>(base + kScratchHit);
     wb.queue[0] = reinterpret_cast<uint32_t *>(base + kScratchQueue0);
     wb.queue[1] = reinterpret_cast<uint32_t *>(base + kScratchQueue1);
     wb.qcount = reinterpret_cast<uint32_t *>(base + kScratchQcount);

@@ -80,9 +80,6 @@ __device__ __forceinline__ uint32_t rng_uint(uint32_t &x, uint32_t L) {
 // the reference, so its cached second variate is discarded and every call runs the loop and
 // returns y * mult.
 __device__ __forceinline__ float rng_normal(uint32_t &x) {
-#ifdef RT_ABL_NONORMAL
-    return 2.0f * rng_uniform(x) - 1.0f;
-#endif
     float a, b, r2;
     do {
         a = 2.0f * rng_uniform(x) - 1.0f;
@@ -180,38 +177,6 @@ __device__ __forceinline__ bool tri_test(float4 q0, float4 q1, float4 q2, v3 o, 
     return !(u < 0.f || v < 0.f || t < 0.f || u + v > 1.f);
 }
 
-// The same test with the distance first: t needs the determinant and the stored normal only (about 30
-// operations); the other two rows of the inverse (about 30 more) are skipped when no lane of the wave has
-// a distance that could still win (0 <= t < its limit).  Every value that is compared is computed by the
-// same operations as in tri_test.  `active` = this lane takes part; returns hit && t < tLimit.
-__device__ __forceinline__ bool tri_test_tfirst(float4 q0, float4 q1, float4 q2, v3 o, v3 d, float tLimit, bool active,
-                                                float &tOut) {
-    const float m00 = q0.w, m01 = q1.x, m02 = q1.y;
-    const float m10 = q1.z, m11 = q1.w, m12 = q2.x;
-    const float m20 = -d.x, m21 = -d.y, m22 = -d.z;
-    const float wx = o.x - q0.x, wy = o.y - q0.y, wz = o.z - q0.z;
-    const float ca = m11 * m22 - m21 * m12;
-    const float cb = m01 * m22 - m21 * m02;
-    const float cc = q2.y;
-    const float ood = 1.f / ((m00 * ca - m10 * cb) + m20 * cc);
-    const float i02 = cc * ood;
-    const float i12 = q2.z * ood;
-    const float i22 = q2.w * ood;
-    const float t = (i02 * wx + i12 * wy) + i22 * wz;
-    tOut = t;
-    const bool tOk = active && !(t < 0.f) && t < tLimit;
-    if (__ballot(tOk) == 0ull) return false;
-    const float i00 = ca * ood;
-    const float i10 = -(m10 * m22 - m20 * m12) * ood;
-    const float i20 = (m10 * m21 - m20 * m11) * ood;
-    const float i01 = -cb * ood;
-    const float i11 = (m00 * m22 - m20 * m02) * ood;
-    const float i21 = -(m00 * m21 - m20 * m01) * ood;
-    const float u = (i00 * wx + i10 * wy) + i20 * wz;
-    const float v = (i01 * wx + i11 * wy) + i21 * wz;
-    return tOk && !(u < 0.f || v < 0.f || u + v > 1.f);
-}
-
 // Closest hit (BVH::intersect, main.cpp:560-605): the minimum-t triangle among all triangles the
 // ray hits.  A hit needs t < INF (1e4): the reference prunes every subtree at that distance until a
 // first hit is found.
@@ -229,7 +194,7 @@ __device__ __forceinline__ bool tri_test_tfirst(float4 q0, float4 q1, float4 q2,
 // height bound (kStack inner levels) is what keeps the stack from overflowing.
 constexpr int kSentinel = 0x7FFFFFFF;  // "stack is empty": never a node index, never a leaf reference
 
-template <bool COUNT, int EXIT_LANES = 0, bool HELP = false, bool DMA = false>
+template <bool COUNT, int EXIT_LANES = 0, bool HELP = false>
 struct Traversal {
     struct f2 {
         float x, y;
@@ -245,7 +210,6 @@ struct Traversal {
     int sp;
     int *stack;   // this lane's column of the LDS stack
     uint32_t *xchg;  // HELP: 128 words of LDS owned by this wave
-    uint4 *stage;    // DMA: 128 x 16 bytes of LDS owned by this wave, node words land here (may alias xchg)
 
     // lane_stack: &lds[threadIdx.x]
     __device__ __forceinline__ void bind(int *lane_stack) { stack = lane_stack; }
@@ -313,24 +277,7 @@ struct Traversal {
         const uint32_t nodes0 = st.nodes, tris0 = st.tris;
         while (cur >= 0 && cur != kSentinel) {
             const uint4 *np = S.nodes + 2 * (size_t)cur;
-            uint4 n0, n1;
-            if (DMA) {
-                // The two halves of the node go straight into LDS (lane l's 16 bytes land at stage[l] and
-                // stage[64 + l]) and come back with two conflict-free ds_read_b128: a per-lane gather that
-                // returns into registers costs the CU about one cycle per lane and instruction, the
-                // direct-to-LDS form a third of that when the line is in L1.
-                typedef const __attribute__((address_space(1))) void *gptr;
-                typedef __attribute__((address_space(3))) void *lptr;
-                __builtin_amdgcn_global_load_lds((gptr)np, (lptr)stage, 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr)(np + 1), (lptr)(stage + 64), 16, 0, 0);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const uint32_t l = threadIdx.x & 63u;
-                n0 = stage[l];
-                n1 = stage[64 + l];
-            } else {
-                n0 = np[0];
-                n1 = np[1];
-            }
+            const uint4 n0 = np[0], n1 = np[1];
             if (COUNT) ++st.nodes;
             // Conservative slab test on the node's 16-bit grid boxes.  The host rounded every box
             // outward and added two guard cells per side, far more than the rounding of these FMAs
@@ -415,22 +362,10 @@ struct Traversal {
             bool hit = false;
             const uint32_t firstOfSrc = (uint32_t)__shfl((int)first, src);  // every lane takes part in the shuffle
             const uint32_t myTri = has ? first : firstOfSrc + 1u;
-#ifdef RT_TRI_TFIRST
-            {
-                const float lim = __shfl(tBest, src);
-                float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
-                if (has || help) {
-                    const float4 *tp = S.tris + 4 * (size_t)myTri;
-                    a0 = tp[0], a1 = tp[1], a2 = tp[2];
-                }
-                hit = tri_test_tfirst(a0, a1, a2, ro, rd, lim, has || help, t);
-            }
-#else
             if (has || help) {
                 const float4 *tp = S.tris + 4 * (size_t)myTri;
                 hit = tri_test(tp[0], tp[1], tp[2], ro, rd, t);
             }
-#endif
             if (help) xchg[64 + hrank] = __float_as_uint(hit ? t : kInf);
             __builtin_amdgcn_wave_barrier();
             if (COUNT) {  // passes of the wave through the triangle test: one, two if a second triangle found no helper
@@ -536,8 +471,7 @@ struct PathState {
 constexpr uint32_t kLdsLights = 64;
 constexpr uint32_t kLdsMats = 64;
 struct LightCache {
-    const float4 *recs;  // LDS: 4 x float4 per cached light, light-list order; q3.w = zero-determinant threshold
-    const float4 *sph;   // LDS: per cached light (bounding-sphere centre xyz, 2 * padded radius^2)
+    const float4 *recs;  // LDS: 4 x float4 per cached light, light-list order
     const int *ids;      // LDS: leaf-order triangle position of each cached light
     const float4 *mats;  // LDS: 2 x float4 per cached material
     uint32_t n;          // lights cached: min(S.nlights, kLdsLights)
@@ -546,7 +480,6 @@ struct LightCache {
 };
 struct LightCacheStorage {
     float4 recs[4 * kLdsLights];
-    float4 sph[kLdsLights];
     float4 mats[2 * kLdsMats];
     int ids[kLdsLights];
 };
@@ -559,20 +492,7 @@ __device__ __forceinline__ LightCache load_light_cache(const DevScene &S, LightC
     for (uint32_t e = threadIdx.x; e < 2u * nm; e += kBlock) st.mats[e] = reinterpret_cast<const float4 *>(S.mats)[e];
     for (uint32_t k = threadIdx.x; k < n; k += kBlock) st.ids[k] = (int)S.lights[k];
     __syncthreads();
-    // Per cached light, for light_pdf's candidate filter: a sphere around the triangle (centroid, largest
-    // vertex distance padded by 1e-3) and the size of cross(AB, AC) . d below which the exact test's
-    // determinant may round to zero.
-    for (uint32_t k = threadIdx.x; k < n; k += kBlock) {
-        const float4 q0 = st.recs[4 * k], q1 = st.recs[4 * k + 1], q2 = st.recs[4 * k + 2];
-        const v3 A = mk(q0.x, q0.y, q0.z), AB = mk(q0.w, q1.x, q1.y), AC = mk(q1.z, q1.w, q2.x);
-        const v3 c = A + (AB + AC) * (1.f / 3.f);
-        const v3 da = A - c, db = (A + AB) - c, dc = (A + AC) - c;
-        const float r2 = __builtin_fmaxf(dot(da, da), __builtin_fmaxf(dot(db, db), dot(dc, dc))) * 1.002001f;
-        st.sph[k] = make_float4(c.x, c.y, c.z, 2.f * r2);
-        st.recs[4 * k + 3].w = 1.0e-3f * __builtin_sqrtf(dot(AB, AB) * dot(AC, AC));
-    }
-    __syncthreads();
-    return LightCache{st.recs, st.sph, st.ids, st.mats, n, nm, lane_stack};
+    return LightCache{st.recs, st.ids, st.mats, n, nm, lane_stack};
 }
 
 __device__ __forceinline__ DevMaterial material(const DevScene &S, const LightCache &LC, uint32_t m) {
@@ -674,42 +594,14 @@ template <bool TREE>
 __device__ __forceinline__ float light_pdf(const DevScene &S, const LightCache &LC, v3 x, v3 w, int self,
                                            uint32_t &tests) {
     float ps = 0.f;
-#ifdef RT_ABL_NOLIGHT
-    return 0.f;
-#endif
     if (TREE) {
         ps = light_pdf_tree(S, LC.stack, x, w, self, tests);
         if (ps < kEps || __builtin_isnan(ps) || __builtin_isinf(ps)) return 0.f;
         return ps / (float)S.nlights;
     }
-    // Lights cached in LDS: a cheap conservative filter picks the candidates, then each lane runs the
-    // exact test on ITS candidates only, in light-list order (the order the reference adds the terms
-    // in).  Most directions cross none or one of a few small lights, so the lanes of a wave spend a
-    // couple of exact tests instead of one per light.  A light is a candidate unless
-    //   * the ray's line passes its bounding sphere's centre at more than sqrt(2 R^2 + 8e-6 |c - x|^2), or
-    //     the centre lies further than that behind the origin: the exact test's u, v, t carry a relative rounding error
-    //     of a few 1e-7 |c - x| / (|AB| |cos(N, d)| sin(AB, AC)), which the 1e-3 padding of R and the 2.8e-3
-    //     |c - x| slack cover for every ray that is not filtered by the next rule, and
-    //   * |N . d| > 1e-3 |AB| |AC|: below that the determinant may round to zero, and the reference then
-    //     accepts a NaN "hit" that wipes the whole sum (main.cpp:483, 779) -- such rays go to the exact
-    //     test whatever the sphere says.
-    // Comparisons are written so that a NaN makes the light a candidate.
-    unsigned long long cand = 0ull;
     for (uint32_t k = 0; k < LC.n; ++k) {
         if (LC.ids[k] == self) continue;
         ++tests;
-        const float4 sp = LC.sph[k], q2 = LC.recs[4 * k + 2];
-        const v3 oc = mk(sp.x - x.x, sp.y - x.y, sp.z - x.z);
-        const float oc2 = dot(oc, oc), b = dot(oc, w);
-        const float bound = sp.w + 8.0e-6f * oc2;
-        const float b2 = b * b;
-        const bool outside = (oc2 - b2 > bound) || (b < 0.f && b2 > bound);  // off the line, or centre > radius behind
-        const bool steep = __builtin_fabsf(dot(mk(q2.y, q2.z, q2.w), w)) > LC.recs[4 * k + 3].w;
-        if (!(outside && steep)) cand |= 1ull << k;
-    }
-    while (cand) {
-        const uint32_t k = (uint32_t)__builtin_ctzll(cand);
-        cand &= cand - 1ull;
         const float4 *tp = LC.recs + 4 * k;
         float t;
         if (tri_test(tp[0], tp[1], tp[2], x, w, t)) ps += light_term(tp[2], tp[3], x, w, t);

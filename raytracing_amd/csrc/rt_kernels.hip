@@ -213,10 +213,15 @@ constexpr uint32_t kShards = 8;           // work cursors of wf_extend (see ther
 constexpr uint32_t kCursorStride = 1024;  // words between cursors
 static_assert(kShards * kCursorStride == rt::kWfCursorWords, "cursor buffer size");
 
-constexpr size_t kRec = rt::kWfRecStride;  // float4s between consecutive records in `ray` and in `state`
+// Path i's record is 40 bytes: 32 contiguous ones that hold the ray (what wf_extend reads) and 8 apart; a
+// lane moves it with two 16-byte and one 8-byte access.  It holds what the next bounce needs and nothing else.  The radiance a path has gathered lives apart (it changes
+// only when a path meets an emitter) and the depth left is the same for every path of a bounce, so
+// neither travels through the shading kernel's loads and stores.
 struct WfView {
-    float4 *ray;    // [kRec i] = (o.xyz, d.x)  [kRec i + 1] = (d.y, d.z, hit t, bits(hit triangle))
-    float4 *state;  // [kRec i] = (throughput.xyz, bits(rng))  [kRec i + 1] = (radiance.xyz, bits(depth left))
+    float4 *ray;    // [2i] = (o.xyz, d.x)  [2i+1] = (d.y, d.z, throughput.x, throughput.y)
+    float2 *c;      // [i] = (throughput.z, bits(rng))
+    float4 *lum;    // [i] = (radiance gathered so far .xyz, 0)
+    float2 *hit;    // [j] = (hit t, bits(hit triangle)) of the ray at POSITION j of the queue being traced
     uint32_t cap;
 };
 
@@ -238,10 +243,10 @@ __global__ __launch_bounds__(kBlock) void wf_generate(DevScene S, rt::RenderPara
         const uint32_t px = pix % rp.W, py = pix / rp.W;
         uint32_t rng = rng_seed(counter_seed(pix, sample, rp.seed));
         const v3 d = primary_direction(S, px, py, rp.W, rp.H, rng);
-        V.ray[kRec * (size_t)i] = make_float4(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2], d.x);
-        V.ray[kRec * (size_t)i + 1] = make_float4(d.y, d.z, 0.f, 0.f);
-        V.state[kRec * (size_t)i] = make_float4(1.f, 1.f, 1.f, __uint_as_float(rng));
-        V.state[kRec * (size_t)i + 1] = make_float4(0.f, 0.f, 0.f, __uint_as_float(rp.max_depth));
+        V.ray[2 * (size_t)i] = make_float4(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2], d.x);
+        V.ray[2 * (size_t)i + 1] = make_float4(d.y, d.z, 1.f, 1.f);
+        V.c[i] = make_float2(1.f, __uint_as_float(rng));
+        V.lum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         qcount[0] = npaths;
@@ -269,24 +274,16 @@ template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const uint32_t *__restrict__ queue,
                                                      const uint32_t *__restrict__ qcount_in,
                                                      uint32_t *__restrict__ qcount_zero, uint32_t *__restrict__ cursors) {
-#ifdef RT_NODE_DMA
-    __shared__ int s_stack[RT_NODE_DMA * kBlock];  // the host caps the tree height at RT_NODE_DMA for this build
-    __shared__ uint4 s_stage[4][128];
-    Traversal<COUNT, kExitLanes, true, true> T;
-    T.stage = s_stage[threadIdx.x >> 6];
-    T.xchg = reinterpret_cast<uint32_t *>(s_stage[threadIdx.x >> 6]);  // triangle phase only: no DMA in flight then
-#else
     __shared__ int s_stack[kStack * kBlock];
     __shared__ uint32_t s_xchg[4][128];
     Traversal<COUNT, kExitLanes, true> T;
     T.xchg = s_xchg[threadIdx.x >> 6];
-#endif
     const uint32_t count = *qcount_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) *qcount_zero = 0u;  // the queue the next shade pass fills
     const uint32_t lane = threadIdx.x & 63u;
     T.idle();
     T.bind(s_stack + threadIdx.x);
-    uint32_t slot = 0, segs = 0;
+    uint32_t qpos = 0, segs = 0;  // queue position of this lane's ray: where its hit goes
     bool hasRay = false;
     uint32_t chunkNext = 0, chunkEnd = 0;  // wave-uniform
     uint32_t shard = blockIdx.x % kShards, dry = 0;  // wave-uniform: current shard, shards found empty in a row
@@ -294,7 +291,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
     TraceStats st{0, 0, 0, 0};
     for (;;) {
         if (hasRay && T.done()) {
-            reinterpret_cast<float2 *>(V.ray + kRec * (size_t)slot + 1)[1] = make_float2(T.tBest, __int_as_float(T.triBest));
+            V.hit[qpos] = make_float2(T.tBest, __int_as_float(T.triBest));
             hasRay = false;
             ++segs;
         }
@@ -327,9 +324,9 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
                 const uint32_t avail = chunkEnd - chunkNext;
                 const uint32_t take = avail < (uint32_t)nIdle - given ? avail : (uint32_t)nIdle - given;
                 if (!hasRay && rank >= given && rank < given + take) {
-                    const uint32_t j = chunkNext + (rank - given);
-                    slot = queue ? queue[j] : j;
-                    const float4 r0 = V.ray[kRec * (size_t)slot], r1 = V.ray[kRec * (size_t)slot + 1];
+                    qpos = chunkNext + (rank - given);
+                    const uint32_t slot = queue ? queue[qpos] : qpos;
+                    const float4 r0 = V.ray[2 * (size_t)slot], r1 = V.ray[2 * (size_t)slot + 1];
                     T.start(S, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y));
                     hasRay = true;
                 }
@@ -356,7 +353,7 @@ template <bool TREE>
 __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const uint32_t *__restrict__ queue,
                                                     const uint32_t *__restrict__ qcount_in,
                                                     uint32_t *__restrict__ queue_out, uint32_t *__restrict__ qcount_out,
-                                                    uint32_t *__restrict__ cursors) {
+                                                    uint32_t *__restrict__ cursors, uint32_t depth) {
     __shared__ uint32_t s_buf[kAppendBuf];
     __shared__ uint32_t s_count, s_base;
     __shared__ LightCacheStorage s_lights;
@@ -371,27 +368,45 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const u
     // every thread of the workgroup runs the same number of rounds: the barriers below are uniform
     const uint32_t stride = gridDim.x * kBlock;
     const uint32_t rounds = (count + stride - 1u) / stride;
-    for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t j = r * stride + blockIdx.x * kBlock + threadIdx.x;
+    // A round's path needs three dependent trips to memory: its queue entry, its record, the triangle it
+    // hit.  The hit lies at the queue POSITION (wf_extend stores it there), so it does not wait for the
+    // queue entry, and both are fetched one round ahead: what a round still waits for is one trip, the
+    // record and the triangle side by side.
+    uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t iNext = 0;
+    float2 hNext = make_float2(0.f, 0.f);
+    if (j < count) {
+        iNext = queue ? queue[j] : j;
+        hNext = V.hit[j];
+    }
+    for (uint32_t r = 0; r < rounds; ++r, j += stride) {
         bool alive = false;
-        uint32_t i = 0;
+        const uint32_t i = iNext;
+        const float2 h = hNext;
         if (j < count) {
-            i = queue ? queue[j] : j;
-            const float4 r0 = V.ray[kRec * (size_t)i], r1 = V.ray[kRec * (size_t)i + 1];
-            const float4 s0 = V.state[kRec * (size_t)i], s1 = V.state[kRec * (size_t)i + 1];
+            const float4 r0 = V.ray[2 * (size_t)i], r1 = V.ray[2 * (size_t)i + 1];
+            const float2 r2 = V.c[i];
+            const uint32_t jn = j + stride;
+            if (jn < count) {
+                iNext = queue ? queue[jn] : jn;
+                hNext = V.hit[jn];
+            }
             PathState P;
             P.o = mk(r0.x, r0.y, r0.z);
             P.d = mk(r0.w, r1.x, r1.y);
-            P.T = mk(s0.x, s0.y, s0.z);
-            P.L = mk(s1.x, s1.y, s1.z);
-            P.rng = __float_as_uint(s0.w);
-            P.depth = __float_as_uint(s1.w);
-            alive = shade_hit<TREE>(S, LC, P, r1.z, __float_as_int(r1.w), lightTests);
-            V.state[kRec * (size_t)i + 1] = make_float4(P.L.x, P.L.y, P.L.z, __uint_as_float(P.depth));
+            P.T = mk(r1.z, r1.w, r2.x);
+            P.L = mk(0.f, 0.f, 0.f);
+            P.rng = __float_as_uint(r2.y);
+            P.depth = depth;  // rayDepth of every hit of this bounce (main.cpp:1188-1199)
+            alive = shade_hit<TREE>(S, LC, P, h.x, __float_as_int(h.y), lightTests);
+            if (P.L.x != 0.f || P.L.y != 0.f || P.L.z != 0.f) {  // the path met an emitter (or went NaN): 0 + x == x, so
+                const float4 l = V.lum[i];                        // the stored sum is what a carried one would be
+                V.lum[i] = make_float4(l.x + P.L.x, l.y + P.L.y, l.z + P.L.z, 0.f);
+            }
             if (alive) {
-                V.ray[kRec * (size_t)i] = make_float4(P.o.x, P.o.y, P.o.z, P.d.x);
-                V.ray[kRec * (size_t)i + 1] = make_float4(P.d.y, P.d.z, 0.f, 0.f);
-                V.state[kRec * (size_t)i] = make_float4(P.T.x, P.T.y, P.T.z, __uint_as_float(P.rng));
+                V.ray[2 * (size_t)i] = make_float4(P.o.x, P.o.y, P.o.z, P.d.x);
+                V.ray[2 * (size_t)i + 1] = make_float4(P.d.y, P.d.z, P.T.x, P.T.y);
+                V.c[i] = make_float2(P.T.z, __uint_as_float(P.rng));
             }
         }
         const unsigned long long mask = __ballot(alive);
@@ -426,7 +441,7 @@ __global__ __launch_bounds__(kBlock) void wf_accumulate(WfView V, uint32_t W, ui
         v3 acc = first ? mk(0.f, 0.f, 0.f) : mk(sum[3 * (size_t)pix], sum[3 * (size_t)pix + 1], sum[3 * (size_t)pix + 2]);
         for (uint32_t s = 0; s < nslots; ++s) {
             const size_t i = (size_t)s * npix + j;
-            const float4 l = V.state[kRec * i + 1];
+            const float4 l = V.lum[i];
             acc = acc + mk(l.x, l.y, l.z);
         }
         sum[3 * (size_t)pix] = acc.x;
@@ -465,11 +480,7 @@ __global__ void k_rng_selftest(const uint32_t *__restrict__ seeds, uint32_t nsee
 inline uint32_t pixel_grid(uint32_t W, uint32_t H) { return ((W + 15u) / 16u) * ((H + 15u) / 16u); }
 inline uint32_t ceil_blocks(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 constexpr uint32_t kPersistentBlocks = 256u * 8u;  // 256 CUs x 8 workgroups for grid-stride kernels
-#ifdef RT_NODE_DMA
-constexpr uint32_t kExtendBlocks = 256u * 5u;      // 256 CUs x 5 resident workgroups (stack + 8 KB node staging)
-#else
 constexpr uint32_t kExtendBlocks = 256u * 6u;      // 256 CUs x 6 resident workgroups (24 KB of LDS each)
-#endif
 
 }  // namespace
 
@@ -530,7 +541,7 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
     // `slots` = whole frames of samples in flight per pass; the host guarantees 1 <= slots and
     // slots * npix <= wb.capacity.  A pixel's samples are added in sample order whatever the pass
     // boundaries are (wf_accumulate continues from the stored sum), so the result does not depend on slots.
-    WfView V{wb.ray, wb.state, wb.capacity};
+    WfView V{wb.ray, wb.c, wb.lum, wb.hit, wb.capacity};
     uint32_t done = 0;
     bool first = true;
     while (done < rp.spp_count) {
@@ -557,8 +568,8 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
                                    wb.qcount + out, wb.cursors);
             timer.end(stream);
             timer.begin(kKernShade, stream);
-            hipLaunchKernelGGL(S.light_tree ? wf_shade<true> : wf_shade<false>, dim3(grid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in, wb.queue[out],
-                               wb.qcount + out, wb.cursors);
+            hipLaunchKernelGGL(S.light_tree ? wf_shade<true> : wf_shade<false>, dim3(grid), dim3(kBlock), 0, stream, S, V,
+                               qin, wb.qcount + in, wb.queue[out], wb.qcount + out, wb.cursors, rp.max_depth - (rp.max_depth ? b : 0u));
             timer.end(stream);
         }
         const uint32_t agrid = (npix + kBlock - 1) / kBlock < kPersistentBlocks ? (npix + kBlock - 1) / kBlock

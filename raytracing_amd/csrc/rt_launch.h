@@ -79,28 +79,22 @@ struct RenderParams {
     uint32_t seed;
 };
 
-// Scratch of the wavefront pipeline: path records for `capacity` paths (64 B each, as four 16-byte
-// quarters so that a lane moves a record with four loads or stores: the vector-memory path charges
-// per lane and instruction, not per byte), two index queues, queue counters.  Owned by the scene,
-// sized on first use.
-// Record layout: RT_REC_STRIDE 2 = two arrays (ray halves, state halves); 4 = one array of 64-byte
-// records, ray half then state half (state = ray + 2), so that a path touched through an index queue
-// costs one 64-byte sector instead of two half-used ones.
-#ifndef RT_REC_STRIDE
-#define RT_REC_STRIDE 2
-#endif
-constexpr size_t kWfRecStride = RT_REC_STRIDE;
-static_assert(kWfRecStride == 2 || kWfRecStride == 4, "record stride");
+// Scratch of the wavefront pipeline for `capacity` paths in flight, 72 bytes per path: a 40-byte record
+// (32 contiguous bytes of ray + 8 apart; two 16-byte and one 8-byte access per lane: the vector-memory
+// path charges per lane and instruction, the memory system per sector), the radiance gathered so far, the hit of the
+// bounce being traced, two index queues; plus queue counters and work cursors.  Owned by the scene,
+// grown on demand.
 constexpr size_t kWfCursorWords = 8 * 1024;  // 8 cursors, 4 KB apart (rt_kernels.hip: kShards x kCursorStride)
+constexpr size_t kWfBytesPerPath = 16 + 16 + 8 + 16 + 8 + 4 + 4;
 struct WavefrontBuffers {
     uint32_t capacity = 0;
-    float4 *rec = nullptr;    // the allocation behind ray and state: 4 x capacity float4
-    float4 *ray = nullptr;    // 2 x capacity: [2i] = (o.xyz, d.x)  [2i+1] = (d.y, d.z, hit t, bits(hit triangle))
-    float4 *state = nullptr;  // 2 x capacity: [2i] = (throughput.xyz, bits(rng))  [2i+1] = (radiance.xyz, bits(depth left))
+    float4 *ray = nullptr;    // 2 x capacity: [2i] = (o.xyz, d.x)  [2i+1] = (d.y, d.z, throughput.x, throughput.y)
+    float2 *c = nullptr;      // capacity: (throughput.z, bits(rng))
+    float4 *lum = nullptr;    // capacity: (radiance gathered so far .xyz, 0)
+    float2 *hit = nullptr;    // capacity: (hit t, bits(hit triangle)) by position in the queue being traced
     uint32_t *queue[2] = {nullptr, nullptr};  // path indices alive in the current / next bounce
     uint32_t *qcount = nullptr; // [0], [1]: queue lengths (device)
     uint32_t *cursors = nullptr; // work cursors of the extend kernel, kWfCursorWords words
-
 };
 
 hipError_t launch_intersect(const rtd::DevScene &S, uint64_t n, const float *o, const float *d, uint32_t *prim_id,

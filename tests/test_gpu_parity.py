@@ -281,7 +281,7 @@ def test_scratch_is_grow_only_and_sized_by_the_call(scene_dir, oracle_mod):
     per_frame = W * H * 72
     gpu.render(W, H, 1, rng_mode=1, pipeline=rt.PIPE_WAVEFRONT)
     b1 = gpu.stats()["device_bytes"] - base
-    assert per_frame <= b1 < per_frame + 40000            # one frame of 72-byte records + counters and cursors
+    assert per_frame <= b1 < per_frame + 40000            # one frame of 72 bytes per path + counters and cursors
     gpu.reserve(W, H, 5, pipeline=rt.PIPE_WAVEFRONT)
     b5 = gpu.stats()["device_bytes"] - base
     assert 5 * per_frame <= b5 < 5 * per_frame + 40000
