@@ -140,13 +140,20 @@ def main():
 
     # ---- roofline of the dominant kernel -----------------------------------------------------------
     # Dominant kernel: wf_extend (closest hit of a ray queue) for the wavefront pipeline, k_render_mega
-    # for the megakernel.  Algorithmic bytes per ray segment: 32 B per BVH node visited (one node holds
-    # both child boxes on a 16-bit grid), 48 B per ray/triangle test, plus per segment 36 B of queue traffic in the
-    # wavefront kernel (24 B ray + 4 B queue index read, 8 B hit written); the megakernel instead reads
-    # the 32 B shading record of the hit triangle and 64 B per light-pdf triangle test.  Visit counts
-    # come from the counting build of the same kernels on the same workload (one extra launch outside
-    # the timed region).  Duration: HIP events recorded around every launch of that kernel on its
-    # stream during the timed steps.
+    # for the megakernel.  Three ceilings are priced and the one the kernel sits closest to is reported
+    # as roofline.bound / achieved / peak / frac:
+    #   vmem  the CU's vector-memory path: 64-byte L1 accesses per second (TCP_TOTAL_CACHE_ACCESSES of the
+    #         committed rocprofv3 --pmc pass / the launch time measured here) against the rate a pure
+    #         dependent-gather microbenchmark sustains with its table in L1 (tools/microbench/node_fetch A32:
+    #         two 16-byte loads per lane on a random 32-byte record -- a BVH node visit without the arithmetic)
+    #   valu  SQ_INSTS_VALU x 4 cycles against 256 CUs x 4 SIMDs x the launch's cycles
+    #   hbm   measured L2<->fabric bytes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction) per second
+    #         against the 8 TB/s HBM peak (an upper bound on HBM proper: Infinity Cache hits are in it)
+    # The ALGORITHMIC bytes (32 B per BVH node visited, 48 B per ray/triangle test, 36 B of queue traffic
+    # per segment; visit counts from the counting build of the same kernels on the same workload, one
+    # extra launch outside the timed region) are reported beside them; they are served by L1/L2/Infinity
+    # Cache -- the 83 MB scene stays on chip -- so their rate is not bounded by HBM.
+    # Duration: HIP events recorded around every launch of that kernel on its stream during the timed steps.
     scene.set_counting(True)
     scene.reset_counters(stream)
     count_spp = min(spp_gpu, 4)
@@ -166,24 +173,46 @@ def main():
         bytes_per_seg = 32.0 * n_node + 48.0 * n_tri + 36.0
     k_ms, k_launches = ktimes[kind]
     launch_ms = k_ms / max(k_launches, 1)
+    launch_s = launch_ms * 1e-3
     segs_per_launch = segs / float(max(k_launches, 1))
-    achieved = segs_per_launch * bytes_per_seg / (launch_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):  # HBM-side bytes per launch from the committed rocprofv3 --pmc passes
-        rec = json.load(open(tpath)).get("%s/%s" % (args.workload, kname))
+    algorithmic = segs_per_launch * bytes_per_seg / launch_s / 1e9
+    ceilings, traffic, pmc_src = {}, None, None
+    rpath = os.path.join(ROOT, "profiles", "pmc_rates.json")
+    if os.path.exists(rpath):
+        rates = json.load(open(rpath))
+        rec = rates["kernels"].get(kname) if rates.get("workload") == args.workload else None
         if rec:
-            traffic = rec["bytes_per_launch"]
-    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            pmc_src = rates["source"]
+            traffic = rec.get("fabric_bytes")
+            if traffic:
+                ceilings["hbm"] = {"achieved": round(traffic / launch_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+            peak = rates.get("vmem_gather_peak")
+            if peak and "l1_accesses" in rec:
+                ceilings["vmem"] = {"achieved": round(rec["l1_accesses"] / launch_s / 1e9, 1),
+                                    "peak": round(peak["lane_loads_per_s"] / 1e9, 1), "unit": "G L1 accesses/s",
+                                    "peak_source": peak["source"]}
+            if "valu_wave_insts" in rec and "gui_active_cycles_sum_xcd" in rec:
+                cycles = rec["gui_active_cycles_sum_xcd"] / 8.0     # the counter sums the 8 XCDs
+                ceilings["valu"] = {"achieved": round(rec["valu_wave_insts"] * 4.0 / cycles, 1), "peak": 256 * 4.0,
+                                    "unit": "busy SIMDs (wave64 VALU instruction = 4 cycles; cycles from the PMC pass)"}
+    for v in ceilings.values():
+        v["frac"] = round(v["achieved"] / v["peak"], 4)
+    if ceilings:
+        bound = max(ceilings, key=lambda k: ceilings[k]["frac"])
+        top = ceilings[bound]
+    else:   # no committed PMC pass for this workload: only the algorithmic rate is known
+        bound, top = "hbm", {"achieved": round(algorithmic, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(algorithmic / HBM_PEAK_GBS, 5)}
+    roofline = {"bound": bound, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
+                "traffic": traffic, "ceilings": ceilings, "pmc_source": pmc_src,
                 "kernel": kname, "launch_ms": round(launch_ms, 4), "launches": k_launches,
-                "segments_per_launch": round(segs_per_launch, 1), "bytes_per_segment": round(bytes_per_seg, 1),
+                "algorithmic": {"GB/s": round(algorithmic, 1), "of_hbm_peak": round(algorithmic / HBM_PEAK_GBS, 4),
+                                "bytes_per_segment": round(bytes_per_seg, 1), "segments_per_launch": round(segs_per_launch, 1),
+                                "served_by": "L1 / L2 / Infinity Cache (the scene stays on chip): not an HBM rate"},
                 "nodes_per_segment": round(n_node, 2), "tri_tests_per_segment": round(n_tri, 2),
                 "light_tests_per_segment": round(n_light, 2), "segments_per_sample": round(seg_per_sample, 3),
                 "lane_occupancy": {"node_phase": round(c["nodes"] / max(c["node_lane_slots"], 1), 3),
                                    "triangle_phase": round(c["tri_tests"] / max(c["tri_lane_slots"], 1), 3)},
-                "note": "algorithmic bytes are served mostly by L1/L2/Infinity Cache (the scene fits on chip), so "
-                        "achieved can exceed the HBM peak; traffic = measured fabric bytes per launch (rocprofv3 PMC)",
                 "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in ktimes.items() if v[1]}}
 
     # ---- primary-ray closest hit on the 100k-triangle mesh (informational) ----------------------

@@ -349,3 +349,17 @@ def test_gltf_spec_flags(tmp_path):
         rt.load_gltf(spec_path, 64, 48)
     with pytest.raises(rt.RtError):
         rt.load_gltf(spec_path, 64, 48, flags=0x100)                             # unknown flag
+
+
+def test_restated_libm_kernels_match_the_host_libm(tmp_path):
+    """raytracing_amd/csrc/rt_libm.h (glibc's logf and powf kernels as the device evaluates them) against
+    this host's libm, bit for bit, on every 499th float of [0, 1] (the exhaustive run, stride 1, takes
+    half a minute: `tools/check_libm.cpp`).  logf decides the Gaussian samples' accept/reject
+    branches (main.cpp:108-111), powf the gamma curve's image bytes (main.cpp:1228-1231)."""
+    import subprocess
+    exe = str(tmp_path / "check_libm")
+    subprocess.check_call(["g++", "-O2", "-fopenmp", "-ffp-contract=off", os.path.join(ROOT, "tools", "check_libm.cpp"),
+                           "-o", exe])
+    r = subprocess.run([exe, "499"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "logf mismatches 0" in r.stdout and "mismatches 0\n" in r.stdout

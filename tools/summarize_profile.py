@@ -64,6 +64,34 @@ def main():
                 "bytes_per_launch": round((2.0 * f + w) * 1024.0), "fetch_kib_raw": round(f, 1), "write_kib": round(w, 1),
                 "launches": len(per[k]["FETCH_SIZE"]), "source": tag + "_pmc_summary.txt"}
     json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
+    # Per-launch counter means the bench line's ceilings are computed from (bench.py divides them by the
+    # launch time it measures itself), and the gather rate of the vector-memory path from the
+    # microbenchmark output committed next to them.
+    rates = {"source": tag + "_pmc_summary.txt", "workload": workload, "kernels": {}}
+    want = {"TCP_TOTAL_CACHE_ACCESSES_sum": "l1_accesses", "SQ_INSTS_VALU": "valu_wave_insts",
+            "SQ_INSTS_VMEM_RD": "vmem_rd_wave_insts", "SQ_INSTS_VMEM_WR": "vmem_wr_wave_insts",
+            "GRBM_GUI_ACTIVE": "gui_active_cycles_sum_xcd", "TCP_TCC_READ_REQ_sum": "l1_misses_to_l2",
+            "TCC_HIT_sum": "l2_hits", "TCC_MISS_sum": "l2_misses"}
+    for k in per:
+        rec = {}
+        for c, name in want.items():
+            if c in per[k]:
+                rec[name] = sum(per[k][c]) / len(per[k][c])
+                rec["launches"] = len(per[k][c])
+        if "%s/%s" % (workload, k) in traffic:
+            rec["fabric_bytes"] = traffic["%s/%s" % (workload, k)]["bytes_per_launch"]
+        rates["kernels"][k] = rec
+    mb = os.path.join(prof, tag[:3] + "_microbench_node_fetch.txt")
+    if os.path.exists(mb):
+        # first table = 16 KB of records (resident in every L1); A32 = two global_load_dwordx4 per lane on a
+        # random 32-byte record, next address depends on the data: what a BVH node visit does
+        for line in open(mb):
+            f = line.split()
+            if f and f[0] == "A32":
+                rates["vmem_gather_peak"] = {"lane_loads_per_s": float(f[3]) * 1e9 * 2.0,
+                                             "source": os.path.basename(mb) + ": A32, 16 KB table, 2 x 16-byte loads per lane and record"}
+                break
+    json.dump(rates, open(os.path.join(prof, "pmc_rates.json"), "w"), indent=1, sort_keys=True)
     print(open(os.path.join(prof, tag + "_pmc_summary.txt")).read()[:3000])
     print(json.dumps(traffic, indent=1))
 
