@@ -242,6 +242,27 @@ int rt_scene_reserve(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_
 int rt_render_noalloc_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_begin, uint32_t spp_count,
                           uint32_t max_depth, uint32_t seed, float *d_radiance_sum, void *stream);
 
+/* ---- several GPUs of one node, one process (no reference counterpart: its only parallel loop is the
+ * OpenMP loop over pixels, main.cpp:1237) ----
+ * rt_multi_create builds the acceleration structure ONCE on the host, uploads it to every listed GPU
+ * (devices == NULL: GPUs 0..ndev-1) and opens an RCCL communicator over them (ncclCommInitAll; librccl is
+ * loaded on the first call).  rt_multi_render is generateScene's frame with the samples split: GPU g of n
+ * renders the g-th contiguous part of [spp_begin, spp_begin + spp_count) (rt_multi_sample_range) of every
+ * pixel with RT_RNG_COUNTER, all GPUs at once on their own streams; one ncclReduce (sum, fp32, root = the
+ * first GPU) brings the radiance sums together and the result is copied to the host buffer
+ * (width * height * 3 floats).  Because every (pixel, sample) has its own engine the image does not depend
+ * on n, except for the order of the float additions: the reduce adds n partial sums per pixel where one GPU
+ * adds the samples one after the other, a relative difference of at most about n * 2^-24 of a pixel's sum
+ * (bit-identical for n = 1).  rt_multi_scene hands out GPU i's scene, e.g. for rt_tonemap on the result. */
+typedef struct rt_multi rt_multi;
+int rt_multi_create(const rt_scene_desc *desc, const int *devices, int ndev, rt_multi **out);
+void rt_multi_destroy(rt_multi *m);
+int rt_multi_device_count(const rt_multi *m);
+rt_scene *rt_multi_scene(rt_multi *m, int i);
+void rt_multi_sample_range(uint32_t spp_count, int ndev, int g, uint32_t *begin, uint32_t *count);
+int rt_multi_render(rt_multi *m, uint32_t width, uint32_t height, uint32_t spp_begin, uint32_t spp_count,
+                    uint32_t max_depth, uint32_t seed, int pipeline, float *radiance_sum);
+
 /* ---- image: mean, ACES, gamma (main.cpp:1226-1231, 827-838), truncating byte conversion
  * (colorFloatToInt, main.cpp:840-846), PPM writer (printImage, main.cpp:856-864) ---- */
 /* out_float (npixels*3, may be NULL) = SceneFloat contents; out_rgb (npixels*3, may be NULL). */

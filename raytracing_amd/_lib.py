@@ -78,6 +78,13 @@ SIGNATURES = {
                                 C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
     "rt_render_noalloc_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.c_uint32, C.c_void_p, C.c_void_p]),
+    "rt_multi_create": (C.c_int, [C.POINTER(SceneDesc), C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "rt_multi_destroy": (None, [C.c_void_p]),
+    "rt_multi_device_count": (C.c_int, [C.c_void_p]),
+    "rt_multi_scene": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "rt_multi_sample_range": (None, [C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rt_multi_render": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                  C.c_int, C.c_void_p]),
     "rt_scene_reserve": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
     "rt_selftest_rng": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),

@@ -260,6 +260,58 @@ class Scene:
                                        C.c_void_p(out_rgb_ptr) if out_rgb_ptr else None, _stream_ptr(stream)))
 
 
+class MultiScene:
+    """The scene on several GPUs of this node, driven from this one process: one host BVH build, one
+    upload per GPU, an RCCL communicator; render() splits the samples over the GPUs and sum-reduces."""
+
+    def __init__(self, host_scene, devices):
+        if isinstance(host_scene, dict):
+            host_scene = HostScene(**host_scene)
+        self.host = host_scene
+        devs = np.ascontiguousarray(list(devices), dtype=np.int32)
+        self._h = C.c_void_p()
+        d = host_scene._desc()
+        check(_lib.lib().rt_multi_create(C.byref(d), _p(devs), int(devs.size), C.byref(self._h)))
+        self.ndev = int(_lib.lib().rt_multi_device_count(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().rt_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def scene(self, i=0):
+        """GPU i's Scene (borrowed: owned by this MultiScene)."""
+        s = Scene.__new__(Scene)
+        s.host, s.device, s._h = self.host, None, None
+        s._h = C.c_void_p(_lib.lib().rt_multi_scene(self._h, int(i)))
+        s.close = lambda: None
+        return s
+
+    def render(self, width, height, spp, max_depth=6, seed=0, spp_begin=0, pipeline=PIPE_WAVEFRONT):
+        out = np.empty((int(width) * int(height), 3), dtype=np.float32)
+        check(_lib.lib().rt_multi_render(self._h, int(width), int(height), int(spp_begin), int(spp), int(max_depth),
+                                         int(seed), int(pipeline), _p(out)))
+        return out
+
+
+def multi_sample_range(spp, ndev, g):
+    b, c = C.c_uint32(), C.c_uint32()
+    _lib.lib().rt_multi_sample_range(int(spp), int(ndev), int(g), C.byref(b), C.byref(c))
+    return int(b.value), int(c.value)
+
+
 class InputData:
     """What parseGLTF returns in the reference (main.cpp:689-706): image size, depth, sample
     count and the scene, here resident on a GPU."""

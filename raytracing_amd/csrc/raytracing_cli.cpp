@@ -10,6 +10,8 @@
 //     --pipeline P     mega | wavefront      (default mega; wavefront needs --rng counter)
 //     --seed S         seed of the counter RNG (default 0)
 //     --device D       GPU index (default 0)
+//     --gpus N         split the samples over GPUs 0..N-1 of this node and sum-reduce over RCCL (needs
+//                      --rng counter; N = 1 goes through the same path)
 //     --dump-hits F    also write the primary-ray closest hits (uint32 id, float t per pixel) to F
 //     --gltf-spec      read the scene by the glTF 2.0 rules the reference does not follow (RT_GLTF_SPEC)
 // All rendering runs on the GPU through the C ABI of librt_amd.so; there is no CPU fallback.
@@ -36,7 +38,7 @@ int main(int argc, char *argv[]) {
     if (argc < 6) {
         std::fprintf(stderr,
                      "usage: %s <scene.gltf> <width> <height> <samples> <output.ppm> [--depth N] [--rng reference|counter]"
-                     " [--pipeline mega|wavefront] [--seed S] [--device D] [--dump-hits FILE] [--gltf-spec]\n",
+                     " [--pipeline mega|wavefront] [--seed S] [--device D] [--gpus N] [--dump-hits FILE] [--gltf-spec]\n",
                      argv[0]);
         return 2;
     }
@@ -47,7 +49,7 @@ int main(int argc, char *argv[]) {
         return 2;
     }
     uint32_t depth = 6, seed = 0, gltfFlags = 0;
-    int rng = RT_RNG_REFERENCE, pipeline = RT_PIPE_MEGAKERNEL, device = 0;
+    int rng = RT_RNG_REFERENCE, pipeline = RT_PIPE_MEGAKERNEL, device = 0, gpus = 0;
     std::string dumpHits;
     for (int i = 6; i < argc; ++i) {
         std::string a = argv[i];
@@ -61,6 +63,7 @@ int main(int argc, char *argv[]) {
         if (a == "--depth") depth = (uint32_t)std::atol(need("--depth"));
         else if (a == "--seed") seed = (uint32_t)std::strtoul(need("--seed"), nullptr, 0);
         else if (a == "--device") device = std::atoi(need("--device"));
+        else if (a == "--gpus") gpus = std::atoi(need("--gpus"));
         else if (a == "--dump-hits") dumpHits = need("--dump-hits");
         else if (a == "--gltf-spec") gltfFlags = RT_GLTF_SPEC;
         else if (a == "--rng") {
@@ -91,7 +94,17 @@ int main(int argc, char *argv[]) {
     rt_scene_desc desc;
     rt_host_scene_get_desc(hs, &desc);
     rt_scene *scene = nullptr;
-    if (rt_scene_create(&desc, device, &scene) != RT_OK) return die("uploading the scene");
+    rt_multi *multi = nullptr;
+    if (gpus > 0) {
+        if (rng != RT_RNG_COUNTER) {
+            std::fprintf(stderr, "raytracing: --gpus needs --rng counter (the reference's stream is sequential per pixel)\n");
+            return 2;
+        }
+        if (rt_multi_create(&desc, nullptr, gpus, &multi) != RT_OK) return die("uploading the scene to the GPUs");
+        scene = rt_multi_scene(multi, 0);
+    } else if (rt_scene_create(&desc, device, &scene) != RT_OK) {
+        return die("uploading the scene");
+    }
     rt_host_scene_free(hs);
     std::printf("Processed input after %gs\n", now() - start);
 
@@ -112,17 +125,26 @@ int main(int argc, char *argv[]) {
 
     std::vector<float> sum(npix * 3);
     const double t0 = now();
-    if (rt_render(scene, (uint32_t)width, (uint32_t)height, 0, (uint32_t)samples, depth, rng, seed, pipeline, sum.data()) != RT_OK)
+    if (multi) {
+        if (rt_multi_render(multi, (uint32_t)width, (uint32_t)height, 0, (uint32_t)samples, depth, seed, pipeline, sum.data()) != RT_OK)
+            return die("rendering");
+    } else if (rt_render(scene, (uint32_t)width, (uint32_t)height, 0, (uint32_t)samples, depth, rng, seed, pipeline, sum.data()) != RT_OK) {
         return die("rendering");
+    }
     const double renderSeconds = now() - t0;
     std::vector<uint8_t> rgb(npix * 3);
     if (rt_tonemap(scene, sum.data(), npix, (uint32_t)samples, nullptr, rgb.data()) != RT_OK) return die("tone mapping");
     if (rt_write_ppm(outputPath.c_str(), (uint32_t)width, (uint32_t)height, rgb.data()) != RT_OK) return die("writing the image");
-    rt_counters c;
-    if (rt_counters_read(scene, &c) == RT_OK && renderSeconds > 0)
-        std::printf("Traced %llu ray segments in %gs (%.1f Mrays/s)\n", (unsigned long long)c.segments, renderSeconds,
-                    (double)c.segments / renderSeconds * 1e-6);
-    rt_scene_destroy(scene);
+    unsigned long long segments = 0;
+    for (int g = 0; g < (multi ? rt_multi_device_count(multi) : 1); ++g) {
+        rt_counters c;
+        if (rt_counters_read(multi ? rt_multi_scene(multi, g) : scene, &c) == RT_OK) segments += c.segments;
+    }
+    if (renderSeconds > 0)
+        std::printf("Traced %llu ray segments in %gs (%.1f Mrays/s)\n", segments, renderSeconds,
+                    (double)segments / renderSeconds * 1e-6);
+    if (multi) rt_multi_destroy(multi);
+    else rt_scene_destroy(scene);
     std::printf("Finished after %gs", now() - start);
     return 0;
 }

@@ -13,32 +13,12 @@
 
 #include "rt_internal.h"
 #include "rt_launch.h"
+#include "rt_scene.h"
 
 namespace rt {
 static thread_local std::string g_error;
 void set_error(const std::string &msg) { g_error = msg; }
 }  // namespace rt
-
-struct rt_scene {
-    int device = 0;
-    rt::FlatScene flat;
-    rtd::DevScene view{};
-    uint4 *d_nodes = nullptr;
-    float4 *d_tris = nullptr;
-    uint32_t *d_lights = nullptr;
-    uint4 *d_lnodes = nullptr;
-    float4 *d_lrecs = nullptr;
-    rtd::DevMaterial *d_mats = nullptr;
-    unsigned long long *d_counters = nullptr;
-    rt::WavefrontBuffers wf;
-    uint32_t *d_replay = nullptr;  // vertex records of the replay kernel, grown to the largest request
-    uint64_t replay_words = 0;
-    uint64_t device_bytes = 0;
-    bool counting = false;
-    uint32_t nmat = 0;
-    rt::KernelTimer timer;
-    uint64_t host_segments = 0;  // segments of launches whose ray count the host knows (one per ray)
-};
 
 // ---- static scratch of rt_render_noalloc_dev ---------------------------------------------------
 // Path records, index queues, queue counters and work cursors of the wavefront pipeline for
@@ -224,21 +204,37 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     int ndev = rt_device_count();
     if (ndev <= 0) return fail(RT_ERR_HIP, "rt_scene_create: no HIP device is visible");
     if (device < 0 || device >= ndev) return fail(RT_ERR_INVALID, "rt_scene_create: device index out of range");
+    std::shared_ptr<const rt::FlatScene> flat;
+    int rc = rt::build_flat_checked(desc, &flat, "rt_scene_create");
+    if (rc != RT_OK) return rc;
+    return rt::scene_create_from_flat(flat, *desc, device, out);
+}
+
+}  // extern "C"
+
+namespace rt {
+
+int build_flat_checked(const rt_scene_desc *desc, std::shared_ptr<const FlatScene> *out, const char *who) {
+    auto flat = std::make_shared<FlatScene>();
+    try {
+        build_flat_scene(*desc, *flat);
+    } catch (const std::exception &e) {
+        std::string msg = e.what();
+        return fail(msg.find("too many") != std::string::npos ? RT_ERR_LIMIT : RT_ERR_INVALID, std::string(who) + ": " + msg);
+    }
+    if (flat->tree_height > kStackEntries)
+        return fail(RT_ERR_LIMIT, std::string(who) + ": BVH height exceeds the kernels' traversal stack");
+    *out = flat;
+    return RT_OK;
+}
+
+int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene_desc &descRef, int device, rt_scene **out) {
+    const rt_scene_desc *desc = &descRef;
+    *out = nullptr;
     rt_scene *s = new (std::nothrow) rt_scene();
     if (!s) return fail(RT_ERR_INVALID, "rt_scene_create: out of host memory");
     s->device = device;
-    try {
-        rt::build_flat_scene(*desc, s->flat);
-    } catch (const std::exception &e) {
-        delete s;
-        std::string msg = e.what();
-        return fail(msg.find("too many") != std::string::npos ? RT_ERR_LIMIT : RT_ERR_INVALID,
-                    "rt_scene_create: " + msg);
-    }
-    if (s->flat.tree_height > rt::kStackEntries) {
-        delete s;
-        return fail(RT_ERR_LIMIT, "rt_scene_create: BVH height exceeds the kernels' traversal stack");
-    }
+    s->flat = flat;
     DeviceGuard g(device);
     if (!g.ok) {
         delete s;
@@ -251,7 +247,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
             return hip_fail("rt_scene_create: hipGetSymbolAddress(scratch)", es);
         }
     }
-    const rt::FlatScene &f = s->flat;
+    const rt::FlatScene &f = *s->flat;
     std::vector<rtd::DevMaterial> mats(desc->nmat ? desc->nmat : 1);
     for (uint32_t i = 0; i < desc->nmat; ++i) {
         const rt_material &m = desc->materials[i];
@@ -323,6 +319,10 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out) {
     return RT_OK;
 }
 
+}  // namespace rt
+
+extern "C" {
+
 void rt_scene_destroy(rt_scene *s) {
     if (!s) return;
     DeviceGuard g(s->device);
@@ -341,13 +341,13 @@ void rt_scene_destroy(rt_scene *s) {
 
 int rt_scene_get_stats(const rt_scene *s, rt_scene_stats *out) {
     if (!s || !out) return fail(RT_ERR_INVALID, "rt_scene_get_stats: null argument");
-    out->ntri = s->flat.ntri;
-    out->nlights = (uint32_t)s->flat.lights.size();
-    out->nnodes = s->flat.nnodes;
-    out->tree_height = s->flat.tree_height;
-    out->build_seconds = s->flat.build_seconds;
+    out->ntri = s->flat->ntri;
+    out->nlights = (uint32_t)s->flat->lights.size();
+    out->nnodes = s->flat->nnodes;
+    out->tree_height = s->flat->tree_height;
+    out->build_seconds = s->flat->build_seconds;
     out->device_bytes = s->device_bytes;
-    out->height_capped_splits = s->flat.capped_splits;
+    out->height_capped_splits = s->flat->capped_splits;
     out->reserved_ = 0;
     return RT_OK;
 }
@@ -356,11 +356,11 @@ int rt_scene_get_flat(const rt_scene *s, float grid[6], uint32_t *nodes, float *
     if (!s) return fail(RT_ERR_INVALID, "rt_scene_get_flat: null scene");
     if (grid)
         for (int a = 0; a < 3; ++a) {
-            grid[a] = s->flat.grid_origin[a];
-            grid[3 + a] = s->flat.grid_cell[a];
+            grid[a] = s->flat->grid_origin[a];
+            grid[3 + a] = s->flat->grid_cell[a];
         }
-    if (nodes) std::memcpy(nodes, s->flat.nodes.data(), (size_t)s->flat.nnodes * 8 * sizeof(uint32_t));
-    if (tris) std::memcpy(tris, s->flat.tris.data(), (size_t)s->flat.ntri * 16 * sizeof(float));
+    if (nodes) std::memcpy(nodes, s->flat->nodes.data(), (size_t)s->flat->nnodes * 8 * sizeof(uint32_t));
+    if (tris) std::memcpy(tris, s->flat->tris.data(), (size_t)s->flat->ntri * 16 * sizeof(float));
     return RT_OK;
 }
 

@@ -1,0 +1,36 @@
+// rt_scene.h -- the device-resident scene behind the opaque rt_scene handle, shared by the translation
+// units that implement the C ABI (rt_abi.hip: one GPU; rt_multi.hip: several GPUs in one process).
+#pragma once
+#include <memory>
+
+#include "rt_internal.h"
+#include "rt_launch.h"
+
+struct rt_scene {
+    int device = 0;
+    std::shared_ptr<const rt::FlatScene> flat;  // host copy of the flattened structure (shared by the scenes of an rt_multi)
+    rtd::DevScene view{};
+    uint4 *d_nodes = nullptr;
+    float4 *d_tris = nullptr;
+    uint32_t *d_lights = nullptr;
+    uint4 *d_lnodes = nullptr;
+    float4 *d_lrecs = nullptr;
+    rtd::DevMaterial *d_mats = nullptr;
+    unsigned long long *d_counters = nullptr;
+    rt::WavefrontBuffers wf;
+    uint32_t *d_replay = nullptr;  // vertex records of the replay kernel, grown to the largest request
+    uint64_t replay_words = 0;
+    uint64_t device_bytes = 0;
+    bool counting = false;
+    uint32_t nmat = 0;
+    rt::KernelTimer timer;
+    uint64_t host_segments = 0;  // segments of launches whose ray count the host knows (one per ray)
+};
+
+namespace rt {
+// Uploads an already built flattened scene to `device`.  `flat` may be shared between scenes (one host
+// BVH build for all GPUs of an rt_multi).  Sets the thread's error message on failure.
+int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene_desc &desc, int device, rt_scene **out);
+// Host side of rt_scene_create: argument checks + BVH build; maps builder exceptions to RT_ERR_*.
+int build_flat_checked(const rt_scene_desc *desc, std::shared_ptr<const FlatScene> *out, const char *who);
+}  // namespace rt

@@ -654,3 +654,42 @@ def test_random_material_soup_renders_bit_exact(oracle_mod, seed, n_emissive):
         assert gpu.counters()["segments"] == c_c["segments"]
     gpu.close()
     orc.close()
+
+
+def test_multi_gpu_entry_point_on_one_gpu(scene_dir, oracle_mod, tmp_path):
+    """rt_multi_create / rt_multi_render with one GPU: the whole path runs -- shared host BVH build, upload,
+    RCCL communicator (ncclCommInitAll over one device), per-GPU stream, ncclReduce -- and the sums equal
+    rt_render's bit for bit (with n GPUs the reduce adds n partial sums per pixel: about n * 2^-24
+    relative).  Also through the command line (`raytracing ... --gpus 1`)."""
+    import os
+    import subprocess
+    import raytracing_amd as rt
+    from conftest import ROOT
+    W, H = 96, 72
+    host, gpu, orc = _load(scene_dir, oracle_mod, "cornell", W, H)
+    with rt.MultiScene(host, [0]) as multi:
+        assert multi.ndev == 1
+        for pipe in (rt.PIPE_WAVEFRONT, rt.PIPE_MEGAKERNEL):
+            want = gpu.render(W, H, 5, max_depth=8, rng_mode=rt.RNG_COUNTER, seed=21, spp_begin=2, pipeline=pipe)
+            got = multi.render(W, H, 5, max_depth=8, seed=21, spp_begin=2, pipeline=pipe)
+            _assert_bits_equal(got, want)
+        ref, _ = orc.render(W, H, 5, max_depth=8, rng_mode=1, seed=21, spp_begin=2)
+        _assert_close(got, ref)
+        assert multi.scene(0).stats()["ntri"] == 36
+        assert not multi.render(W, H, 0, seed=1).any()
+    with pytest.raises(rt.RtError):
+        rt.MultiScene(host, [0, 0])
+    with pytest.raises(rt.RtError):
+        rt.MultiScene(host, [rt.device_count()])
+    path = make_scene(scene_dir, "cornell")
+    exe = os.path.join(ROOT, "raytracing_amd", "bin", "raytracing")
+    outs = []
+    for extra in (["--gpus", "1"], []):
+        out = str(tmp_path / ("multi%d.ppm" % len(outs)))
+        r = subprocess.run([exe, path, str(W), str(H), "4", out, "--rng", "counter", "--pipeline", "wavefront", "--seed", "3"]
+                           + extra, capture_output=True, text=True, cwd=ROOT, timeout=280)
+        assert r.returncode == 0, r.stderr
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] and len(outs[0]) > W * H * 3
+    r = subprocess.run([exe, path, str(W), str(H), "4", str(tmp_path / "x.ppm"), "--gpus", "1"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 2 and "--rng counter" in r.stderr

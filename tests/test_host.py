@@ -363,3 +363,17 @@ def test_restated_libm_kernels_match_the_host_libm(tmp_path):
     r = subprocess.run([exe, "499"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "logf mismatches 0" in r.stdout and "mismatches 0\n" in r.stdout
+
+
+def test_multi_gpu_sample_split_matches_the_python_one():
+    """rt_multi_sample_range (the C ABI's split of a frame's samples over the GPUs of one process) and
+    raytracing_amd.dist.sample_range (one process per GPU) are the same partition: contiguous, complete,
+    the first spp % n parts one sample longer."""
+    import raytracing_amd as rt
+    from raytracing_amd.dist import sample_range
+    for spp in (0, 1, 3, 5, 128, 1024, 4097):
+        for n in (1, 2, 3, 4, 8):
+            parts = [rt.multi_sample_range(spp, n, g) for g in range(n)]
+            assert parts == [sample_range(spp, n, g) for g in range(n)]
+            assert parts[0][0] == 0 and sum(c for _, c in parts) == spp
+            assert all(parts[g][0] + parts[g][1] == parts[g + 1][0] for g in range(n - 1))
