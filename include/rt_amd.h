@@ -101,6 +101,9 @@ typedef struct rt_scene_desc {
     const rt_material *materials;
     uint32_t nmat;
     rt_camera camera;
+    /* InputData::backgroundColor (main.cpp:694): what applyLight returns for a ray that hits nothing
+     * (main.cpp:1190-1192).  The reference never sets it: (0, 0, 0) reproduces it. */
+    float background[3];
 } rt_scene_desc;
 
 typedef struct rt_scene rt_scene;           /* device-resident scene */
@@ -150,12 +153,21 @@ int rt_gltf_load(const char *path, uint32_t width, uint32_t height, rt_host_scen
  * main.cpp:1060-1078); DATA_URI: base64 `data:` buffers (reference: external files only, 875-882);
  * HIERARCHY: a node's world transform is the product along its parent chain whatever the node
  * order, and the camera uses its world transform (reference: one ascending pass, camera local
- * only, main.cpp:1015-1026). */
+ * only, main.cpp:1015-1026);
+ * GLB: `.glb` binary containers (header, JSON chunk, BIN chunk backing the first buffer when it has no
+ * uri; reference: text files with external buffers only, main.cpp:869-882); IOR: KHR_materials_ior.ior per
+ * material (reference: 1.5 always, main.cpp:65).  RT_GLTF_SPEC = all of these.
+ * BACKGROUND: InputData::backgroundColor (main.cpp:694, never set by the reference) from
+ * scenes[scene].extras.backgroundColor = [r, g, b] -- not a glTF feature, hence outside RT_GLTF_SPEC. */
 #define RT_GLTF_STRIDE 1u
 #define RT_GLTF_INDEX_OFFSET 2u
 #define RT_GLTF_DATA_URI 4u
 #define RT_GLTF_HIERARCHY 8u
-#define RT_GLTF_SPEC 15u
+#define RT_GLTF_GLB 16u
+#define RT_GLTF_IOR 32u
+#define RT_GLTF_BACKGROUND 64u
+#define RT_GLTF_SPEC 63u
+#define RT_GLTF_ALL 127u
 int rt_gltf_load_ex(const char *path, uint32_t width, uint32_t height, uint32_t flags, rt_host_scene **out);
 int rt_host_scene_get_desc(const rt_host_scene *hs, rt_scene_desc *out); /* pointers stay owned by hs */
 void rt_host_scene_free(rt_host_scene *hs);

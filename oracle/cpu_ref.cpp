@@ -800,6 +800,10 @@ void orc_tonemap(const float *radiance_sum, uint64_t npixels, uint32_t spp, floa
     }
 }
 
+// InputData::backgroundColor (main.cpp:694): the reference never sets it; a host that does (an opt-in
+// of the build under test) is checked against applyLight's miss branch (main.cpp:1190-1192) with it.
+void orc_scene_set_background(void *h, float r, float g, float b) { asScene(h)->backgroundColor = V(r, g, b); }
+
 // Known-answer probe of the RNG layer (main.cpp:98-111), each group from a freshly seeded engine.
 // raw[4], uni[3], nrm[3], nrm_draws[1] (engine draws used by the 3 normals), ui2[4] =
 // sampleUInt(0,1), ui12[4] = sampleUInt(0,11).

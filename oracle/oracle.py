@@ -51,6 +51,7 @@ def lib():
         L.orc_scene_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                        C.POINTER(Camera)]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_scene_set_background.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
         L.orc_scene_info.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_intersect_rays.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -86,7 +87,7 @@ class OracleScene:
     camera: dict(position, right, up, forward, tan_x, tan_y).
     """
 
-    def __init__(self, tri_verts, tri_material, materials, camera):
+    def __init__(self, tri_verts, tri_material, materials, camera, background=None):
         tv = np.ascontiguousarray(tri_verts, dtype=np.float32).reshape(-1, 9)
         tm = np.ascontiguousarray(tri_material, dtype=np.uint32)
         mats = np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE)
@@ -98,6 +99,8 @@ class OracleScene:
         cam.tan_y = float(camera["tan_y"])
         self.ntri = tv.shape[0]
         self._h = lib().orc_scene_create(_p(tv), _p(tm), self.ntri, _p(mats), mats.shape[0], C.byref(cam))
+        if background is not None:
+            lib().orc_scene_set_background(self._h, *[float(x) for x in background])
 
     def close(self):
         if self._h:

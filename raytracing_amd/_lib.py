@@ -29,7 +29,7 @@ class Material(C.Structure):
 
 class SceneDesc(C.Structure):
     _fields_ = [("tri_verts", C.c_void_p), ("tri_material", C.c_void_p), ("ntri", C.c_uint32),
-                ("materials", C.c_void_p), ("nmat", C.c_uint32), ("camera", Camera)]
+                ("materials", C.c_void_p), ("nmat", C.c_uint32), ("camera", Camera), ("background", C.c_float * 3)]
 
 
 class SceneStats(C.Structure):

@@ -32,7 +32,8 @@ def _stream_ptr(stream):
 class HostScene:
     """A parsed scene file on the host: triangle soup, materials, camera (InputData's host half)."""
 
-    def __init__(self, tri_verts, tri_material, materials, camera):
+    def __init__(self, tri_verts, tri_material, materials, camera, background=(0.0, 0.0, 0.0)):
+        self.background = np.asarray(background, dtype=np.float32).reshape(3)  # InputData::backgroundColor, main.cpp:694
         self.tri_verts = np.ascontiguousarray(tri_verts, dtype=np.float32).reshape(-1, 3, 3)
         self.tri_material = np.ascontiguousarray(tri_material, dtype=np.uint32)
         self.materials = np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE)
@@ -41,7 +42,7 @@ class HostScene:
 
     def as_dict(self):
         return dict(tri_verts=self.tri_verts, tri_material=self.tri_material, materials=self.materials,
-                    camera=self.camera)
+                    camera=self.camera, background=self.background)
 
     def _desc(self):
         d = _lib.SceneDesc()
@@ -54,10 +55,12 @@ class HostScene:
             getattr(d.camera, k)[:] = [float(x) for x in self.camera[k]]
         d.camera.tan_x = float(self.camera["tan_x"])
         d.camera.tan_y = float(self.camera["tan_y"])
+        d.background[:] = [float(x) for x in self.background]
         return d
 
 
-GLTF_STRIDE, GLTF_INDEX_OFFSET, GLTF_DATA_URI, GLTF_HIERARCHY, GLTF_SPEC = 1, 2, 4, 8, 15
+GLTF_STRIDE, GLTF_INDEX_OFFSET, GLTF_DATA_URI, GLTF_HIERARCHY, GLTF_GLB, GLTF_IOR, GLTF_BACKGROUND = 1, 2, 4, 8, 16, 32, 64
+GLTF_SPEC, GLTF_ALL = 63, 127
 
 
 def load_gltf(path, width, height, flags=0):
@@ -80,9 +83,10 @@ def load_gltf(path, width, height, flags=0):
         cam = dict(position=np.array(d.camera.position[:], np.float32), right=np.array(d.camera.right[:], np.float32),
                    up=np.array(d.camera.up[:], np.float32), forward=np.array(d.camera.forward[:], np.float32),
                    tan_x=np.float32(d.camera.tan_x), tan_y=np.float32(d.camera.tan_y))
+        bg = np.array(d.background[:], np.float32)
     finally:
         L.rt_host_scene_free(h)
-    return HostScene(tv, tm, mats, cam)
+    return HostScene(tv, tm, mats, cam, bg)
 
 
 def node_boxes(nodes, grid):

@@ -391,6 +391,9 @@ void build_flat_scene(const rt_scene_desc &desc, FlatScene &out) {
                                  " inner levels, the kernels' traversal stack)");
     if (n && (!desc.tri_verts || !desc.tri_material)) throw std::runtime_error("null triangle arrays");
     if (desc.nmat && !desc.materials) throw std::runtime_error("null material table");
+    for (int k = 0; k < 3; ++k)
+        if (!std::isfinite(desc.background[k]) || desc.background[k] < 0.f)
+            throw std::runtime_error("background colour components must be finite and non-negative");
     for (uint32_t i = 0; i < n; ++i)
         if (desc.tri_material[i] >= desc.nmat) throw std::runtime_error("triangle names a missing material");
     for (size_t i = 0; i < (size_t)n * 9; ++i)

@@ -20,7 +20,14 @@
 //   RT_GLTF_DATA_URI    base64 `data:` buffers
 //   RT_GLTF_HIERARCHY   world transform = product along the parent chain whatever the node order;
 //                       the camera takes its world transform
+//   RT_GLTF_GLB         binary containers: 12-byte header, JSON chunk, optional BIN chunk that backs the
+//                       first buffer when it has no uri
+//   RT_GLTF_IOR         KHR_materials_ior.ior instead of the constant 1.5 (main.cpp:65)
+//   RT_GLTF_BACKGROUND  radiance of a ray that leaves the scene (InputData::backgroundColor,
+//                       main.cpp:694, 1191, which the reference never sets) from
+//                       scenes[scene].extras.backgroundColor = [r, g, b]
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -107,17 +114,54 @@ std::vector<char> decode_base64(const std::string &text, size_t begin, size_t nb
 
 void load(const std::string &path, uint32_t width, uint32_t height, uint32_t flags, rt_host_scene &out) {
     using jsonmin::Value;
-    std::ifstream in(path);
+    std::ifstream in(path, std::ios::binary);
     if (!in) throw std::runtime_error("cannot open scene file " + path);
     std::stringstream ss;
     ss << in.rdbuf();
-    const Value data = jsonmin::parse(ss.str());
+    std::string text = ss.str();
+    std::vector<char> glbBin;
+    bool haveGlbBin = false;
+    if ((flags & RT_GLTF_GLB) && text.size() >= 4 && text.compare(0, 4, "glTF") == 0) {
+        // header: magic, version, total length; then chunks: length, type, payload (4-byte aligned)
+        auto u32 = [&](size_t off) -> uint32_t {
+            if (off + 4 > text.size()) throw std::runtime_error("binary glTF container is truncated");
+            uint32_t v;
+            std::memcpy(&v, text.data() + off, 4);
+            return v;
+        };
+        if (u32(4) != 2u) throw std::runtime_error("binary glTF container version is not 2");
+        const size_t total = u32(8);
+        if (total > text.size() || total < 20) throw std::runtime_error("binary glTF container is truncated");
+        std::string json;
+        bool haveJson = false;
+        for (size_t off = 12; off + 8 <= total;) {
+            const size_t len = u32(off), type = u32(off + 4);
+            if (off + 8 + len > total) throw std::runtime_error("binary glTF chunk runs past the container");
+            if (type == 0x4E4F534Au && !haveJson) {  // "JSON"
+                json.assign(text, off + 8, len);
+                haveJson = true;
+            } else if (type == 0x004E4942u && !haveGlbBin) {  // "BIN\0"
+                glbBin.assign(text.begin() + (std::ptrdiff_t)(off + 8), text.begin() + (std::ptrdiff_t)(off + 8 + len));
+                haveGlbBin = true;
+            }
+            off += 8 + ((len + 3) & ~(size_t)3);
+        }
+        if (!haveJson) throw std::runtime_error("binary glTF container has no JSON chunk");
+        text.swap(json);
+    }
+    const Value data = jsonmin::parse(text);
     const std::string base = dir_of(path);
 
     std::vector<std::vector<char>> buffers;  // main.cpp:874-882
     for (const Value &b : data.at("buffers").a) {
-        const std::string uri = b.at("uri").as_string();
         const size_t nbytes = (size_t)b.at("byteLength").as_index();
+        if ((flags & RT_GLTF_GLB) && !b.contains("uri")) {  // the container's BIN chunk backs the first buffer
+            if (!buffers.empty() || !haveGlbBin) throw std::runtime_error("buffer without uri and no BIN chunk to back it");
+            if (glbBin.size() < nbytes) throw std::runtime_error("BIN chunk shorter than byteLength");
+            buffers.push_back(std::vector<char>(glbBin.begin(), glbBin.begin() + (std::ptrdiff_t)nbytes));
+            continue;
+        }
+        const std::string uri = b.at("uri").as_string();
         if ((flags & RT_GLTF_DATA_URI) && uri.rfind("data:", 0) == 0) {
             const size_t comma = uri.find(";base64,");
             if (comma == std::string::npos) throw std::runtime_error("data URI is not base64");
@@ -170,6 +214,11 @@ void load(const std::string &path, uint32_t width, uint32_t height, uint32_t fla
                 md.emission[1] *= strength;
                 md.emission[2] *= strength;
             }
+            if ((flags & RT_GLTF_IOR) && m.contains("extensions") && m.at("extensions").contains("KHR_materials_ior")) {
+                const Value &ext = m.at("extensions").at("KHR_materials_ior");
+                md.ior = ext.contains("ior") ? ext.at("ior").as_float() : 1.5f;  // the extension's default
+                if (!(md.ior >= 1.f)) throw std::runtime_error("KHR_materials_ior.ior must be at least 1");
+            }
             out.materials.push_back(md);
         }
     }
@@ -194,6 +243,20 @@ void load(const std::string &path, uint32_t width, uint32_t height, uint32_t fla
             if (a.contains("byteOffset")) ad.byteOffset = (size_t)a.at("byteOffset").as_index();
             if (ad.bufferView >= views.size()) throw std::runtime_error("accessor names a missing bufferView");
             accessors.push_back(ad);
+        }
+    }
+
+    out.background[0] = out.background[1] = out.background[2] = 0.f;  // main.cpp:694
+    if ((flags & RT_GLTF_BACKGROUND) && data.contains("scenes")) {
+        const size_t which = data.contains("scene") ? (size_t)data.at("scene").as_index() : 0;
+        const Value &sc = data.at("scenes").idx(which);
+        if (sc.contains("extras") && sc.at("extras").contains("backgroundColor")) {
+            const Value &c = sc.at("extras").at("backgroundColor");
+            for (size_t k = 0; k < 3; ++k) {
+                out.background[k] = c.idx(k).as_float();
+                if (!(out.background[k] >= 0.f) || !std::isfinite(out.background[k]))
+                    throw std::runtime_error("backgroundColor components must be finite and non-negative");
+            }
         }
     }
 
@@ -371,7 +434,7 @@ int rt_gltf_load(const char *path, uint32_t width, uint32_t height, rt_host_scen
 }
 
 int rt_gltf_load_ex(const char *path, uint32_t width, uint32_t height, uint32_t flags, rt_host_scene **out) {
-    if (!path || !out || width == 0 || height == 0 || (flags & ~(uint32_t)RT_GLTF_SPEC)) {
+    if (!path || !out || width == 0 || height == 0 || (flags & ~(uint32_t)RT_GLTF_ALL)) {
         rt::set_error("rt_gltf_load: null argument, zero image size or unknown flag");
         return RT_ERR_INVALID;
     }
@@ -403,6 +466,7 @@ int rt_host_scene_get_desc(const rt_host_scene *hs, rt_scene_desc *out) {
     out->materials = hs->materials.data();
     out->nmat = (uint32_t)hs->materials.size();
     out->camera = hs->camera;
+    for (int k = 0; k < 3; ++k) out->background[k] = hs->background[k];
     return RT_OK;
 }
 

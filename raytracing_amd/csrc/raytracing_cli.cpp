@@ -13,7 +13,9 @@
 //     --gpus N         split the samples over GPUs 0..N-1 of this node and sum-reduce over RCCL (needs
 //                      --rng counter; N = 1 goes through the same path)
 //     --dump-hits F    also write the primary-ray closest hits (uint32 id, float t per pixel) to F
-//     --gltf-spec      read the scene by the glTF 2.0 rules the reference does not follow (RT_GLTF_SPEC)
+//     --gltf-spec      read the scene by the glTF 2.0 rules the reference does not follow (RT_GLTF_SPEC:
+//                      byteStride, index offsets, data URIs, node hierarchy, .glb, KHR_materials_ior)
+//     --gltf-background  take the background colour from scenes[scene].extras.backgroundColor
 // All rendering runs on the GPU through the C ABI of librt_amd.so; there is no CPU fallback.
 #include <chrono>
 #include <cstdio>
@@ -38,7 +40,7 @@ int main(int argc, char *argv[]) {
     if (argc < 6) {
         std::fprintf(stderr,
                      "usage: %s <scene.gltf> <width> <height> <samples> <output.ppm> [--depth N] [--rng reference|counter]"
-                     " [--pipeline mega|wavefront] [--seed S] [--device D] [--gpus N] [--dump-hits FILE] [--gltf-spec]\n",
+                     " [--pipeline mega|wavefront] [--seed S] [--device D] [--gpus N] [--dump-hits FILE] [--gltf-spec] [--gltf-background]\n",
                      argv[0]);
         return 2;
     }
@@ -65,7 +67,8 @@ int main(int argc, char *argv[]) {
         else if (a == "--device") device = std::atoi(need("--device"));
         else if (a == "--gpus") gpus = std::atoi(need("--gpus"));
         else if (a == "--dump-hits") dumpHits = need("--dump-hits");
-        else if (a == "--gltf-spec") gltfFlags = RT_GLTF_SPEC;
+        else if (a == "--gltf-spec") gltfFlags |= RT_GLTF_SPEC;
+        else if (a == "--gltf-background") gltfFlags |= RT_GLTF_BACKGROUND;
         else if (a == "--rng") {
             std::string v = need("--rng");
             if (v == "reference") rng = RT_RNG_REFERENCE;

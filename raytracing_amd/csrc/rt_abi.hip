@@ -315,6 +315,11 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
     }
     v.tan_x = desc->camera.tan_x;
     v.tan_y = desc->camera.tan_y;
+    v.has_background = 0u;
+    for (int k = 0; k < 3; ++k) {
+        v.background[k] = desc->background[k];
+        if (desc->background[k] != 0.f) v.has_background = 1u;
+    }
     *out = s;
     return RT_OK;
 }

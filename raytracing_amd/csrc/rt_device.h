@@ -128,6 +128,8 @@ struct DevScene {
     float lgrid_origin[3], lgrid_cell[3];  // the same for lnodes
     float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];
     float tan_x, tan_y;
+    float background[3];  // InputData::backgroundColor (main.cpp:694): radiance of a ray that hits nothing
+    uint32_t has_background;  // any component nonzero
 };
 
 struct TraceStats {
@@ -437,7 +439,8 @@ __device__ __forceinline__ v3 primary_direction(const DevScene &S, uint32_t px, 
 // exactly one continuation ray, so a sample is a chain of vertices.  sample_vertex() does what is
 // common to every way of evaluating that chain: the random decisions, the next ray, and a record
 // of HOW the vertex combines the radiance L_next coming back along that ray:
-//   kOpNone      miss or depth 0:                      L = 0
+//   kOpNone      depth 0, or a miss under the reference's black background:      L = 0
+//   kOpBackground  miss under a nonzero background colour: L = backgroundColor   (main.cpp:1190-1192)
 //   kOpEmit      depth 1, or a diffuse vertex whose sampled direction is rejected:   L = e
 //   kOpDiffuse   L = color * L_next * (1/pi) * wn / pdf + e      (main.cpp:1139-1140)
 //   kOpMetal     L = color * L_next + e                          (main.cpp:1146)
@@ -447,7 +450,7 @@ __device__ __forceinline__ v3 primary_direction(const DevScene &S, uint32_t px, 
 // numbers, different rounding of the same products); the replay kernel stores the records and
 // evaluates the recursion backwards in the reference's own operation order.
 // ---------------------------------------------------------------------------------------------
-enum VertexOp { kOpNone = 0, kOpEmit, kOpDiffuse, kOpMetal, kOpPass, kOpTint };
+enum VertexOp { kOpNone = 0, kOpEmit, kOpDiffuse, kOpMetal, kOpPass, kOpTint, kOpBackground };
 
 struct Vertex {
     int op;
@@ -627,7 +630,10 @@ __device__ __forceinline__ bool sample_vertex(const DevScene &S, const LightCach
     V.mat = 0u;
     V.wn = 0.f;
     V.pdf = 1.f;
-    if (tri < 0) return false;        // miss: backgroundColor is always (0,0,0), main.cpp:694, 1190
+    if (tri < 0) {                    // miss: backgroundColor, (0,0,0) unless the caller set one (main.cpp:694, 1190)
+        if (S.has_background) V.op = kOpBackground;
+        return false;
+    }
     if (P.depth == 0) return false;   // main.cpp:1195
     const float4 *tp = S.tris + 4 * (size_t)tri;
     const float4 q2 = tp[2], q3 = tp[3];
@@ -723,6 +729,10 @@ __device__ __forceinline__ bool sample_vertex(const DevScene &S, const LightCach
 // Forward evaluation of one vertex: L += T * e, T *= k.
 __device__ __forceinline__ void fold_forward(const DevScene &S, const LightCache &LC, PathState &P, const Vertex &V) {
     if (V.op == kOpNone) return;
+    if (V.op == kOpBackground) {
+        P.L = P.L + P.T * mk(S.background[0], S.background[1], S.background[2]);
+        return;
+    }
     const DevMaterial M = material(S, LC, V.mat);
     const v3 color = mk(M.a.x, M.a.y, M.a.z);
     P.L = P.L + P.T * mk(M.b.x, M.b.y, M.b.z);
@@ -748,6 +758,7 @@ __device__ __forceinline__ bool shade_hit(const DevScene &S, const LightCache &L
 __device__ __forceinline__ v3 fold_backward(const DevScene &S, const LightCache &LC, int op, uint32_t mat, float wn,
                                             float pdf, v3 l) {
     if (op == kOpNone) return mk(0.f, 0.f, 0.f);
+    if (op == kOpBackground) return mk(S.background[0], S.background[1], S.background[2]);
     const DevMaterial M = material(S, LC, mat);
     const v3 color = mk(M.a.x, M.a.y, M.a.z);
     const v3 e = mk(M.b.x, M.b.y, M.b.z);

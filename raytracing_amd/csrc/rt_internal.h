@@ -12,6 +12,7 @@ struct rt_host_scene {
     std::vector<uint32_t> tri_material;  // ntri
     std::vector<rt_material> materials;
     rt_camera camera;
+    float background[3] = {0.f, 0.f, 0.f};  // InputData::backgroundColor (main.cpp:694)
     double parse_seconds = 0.0;
 };
 

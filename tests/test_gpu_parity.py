@@ -21,7 +21,7 @@ def _load(scene_dir, oracle_mod, name, W, H, **kw):
     host = rt.load_gltf(path, W, H)
     gpu = rt.Scene(host, device=0)
     d = host.as_dict()
-    orc = oracle_mod.OracleScene(d["tri_verts"], d["tri_material"], d["materials"], d["camera"])
+    orc = oracle_mod.OracleScene(d["tri_verts"], d["tri_material"], d["materials"], d["camera"], d["background"])
     return host, gpu, orc
 
 
@@ -693,3 +693,37 @@ def test_multi_gpu_entry_point_on_one_gpu(scene_dir, oracle_mod, tmp_path):
     assert outs[0] == outs[1] and len(outs[0]) > W * H * 3
     r = subprocess.run([exe, path, str(W), str(H), "4", str(tmp_path / "x.ppm"), "--gpus", "1"], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 2 and "--rng counter" in r.stderr
+
+
+def test_background_colour_and_per_material_ior(scene_dir, oracle_mod):
+    """Two inputs the reference's InputData has but its loader never sets (main.cpp:65, 694): a background
+    colour (what applyLight returns for a ray that hits nothing, main.cpp:1190-1192) and an index of refraction
+    other than 1.5 (applyLightDielectric, main.cpp:1149-1186).  An open scene (spheres over a ground plane:
+    most paths end in the background) with water- and diamond-like glass: reference stream bit for bit,
+    both throughput pipelines within 1e-5, equal segment counts."""
+    import raytracing_amd as rt
+    W, H = 128, 96
+    path = make_scene(scene_dir, "spheres1m", n_spheres=40, subdiv=2, ground=16)
+    base = rt.load_gltf(path, W, H)
+    mats = base.materials.copy()
+    glass = np.flatnonzero(mats["type"] == 2)
+    assert glass.size >= 1
+    mats["ior"][glass] = np.where(np.arange(glass.size) % 2 == 0, 1.33, 2.4).astype(np.float32)
+    host = rt.HostScene(base.tri_verts, base.tri_material, mats, base.camera, background=(0.35, 0.5, 0.9))
+    gpu = rt.Scene(host, device=0)
+    d = host.as_dict()
+    orc = oracle_mod.OracleScene(d["tri_verts"], d["tri_material"], d["materials"], d["camera"], d["background"])
+    ref0, c0 = orc.render(W, H, 3, max_depth=8, rng_mode=0)
+    gpu.reset_counters()
+    _assert_bits_equal(gpu.render(W, H, 3, max_depth=8, rng_mode=0), ref0)
+    assert gpu.counters()["segments"] == c0["segments"]
+    plain, _ = oracle_mod.OracleScene(d["tri_verts"], d["tri_material"], base.materials, d["camera"]).render(
+        W, H, 3, max_depth=8, rng_mode=0)
+    assert ref0.mean() > 2.0 * plain.mean()               # the sky really lights the scene
+    ref, c_o = orc.render(W, H, 4, max_depth=8, rng_mode=1, seed=5, spp_begin=1)
+    for pipe in (rt.PIPE_MEGAKERNEL, rt.PIPE_WAVEFRONT):
+        gpu.reset_counters()
+        _assert_close(gpu.render(W, H, 4, max_depth=8, rng_mode=1, seed=5, spp_begin=1, pipeline=pipe), ref)
+        assert gpu.counters()["segments"] == c_o["segments"]
+    with pytest.raises(rt.RtError):
+        rt.Scene(rt.HostScene(base.tri_verts, base.tri_material, mats, base.camera, background=(-1, 0, 0)))

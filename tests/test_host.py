@@ -377,3 +377,67 @@ def test_multi_gpu_sample_split_matches_the_python_one():
             assert parts == [sample_range(spp, n, g) for g in range(n)]
             assert parts[0][0] == 0 and sum(c for _, c in parts) == spp
             assert all(parts[g][0] + parts[g][1] == parts[g + 1][0] for g in range(n - 1))
+
+
+def _to_glb(gltf_path, out_path, drop_uri=True):
+    """Packs a .gltf + its single external .bin into a binary container (glTF 2.0, section 4.4)."""
+    import struct
+    doc = json.load(open(gltf_path))
+    blob = open(os.path.join(os.path.dirname(gltf_path), doc["buffers"][0]["uri"]), "rb").read()
+    if drop_uri:
+        del doc["buffers"][0]["uri"]
+    text = json.dumps(doc).encode()
+    text += b" " * (-len(text) % 4)
+    blob += b"\0" * (-len(blob) % 4)
+    total = 12 + 8 + len(text) + 8 + len(blob)
+    with open(out_path, "wb") as f:
+        f.write(struct.pack("<4sII", b"glTF", 2, total))
+        f.write(struct.pack("<II", len(text), 0x4E4F534A) + text)
+        f.write(struct.pack("<II", len(blob), 0x004E4942) + blob)
+    return out_path
+
+
+def test_gltf_glb_ior_background_flags(scene_dir, tmp_path):
+    """The remaining opt-in loader flags: `.glb` containers, KHR_materials_ior, a background colour.  Each is
+    off by default (the reference reads text files with external buffers, fixes ior = 1.5 and never sets its
+    backgroundColor: main.cpp:869-882, 65, 694), and none disturbs a file that does not use it."""
+    import raytracing_amd as rt
+    A = rt.api
+    path = make_scene(scene_dir, "cornell")
+    plain = rt.load_gltf(path, 64, 48)
+    assert (plain.materials["ior"] == np.float32(1.5)).all() and not plain.background.any()
+    # .glb: same triangles, materials, camera
+    glb = _to_glb(path, str(tmp_path / "cornell.glb"))
+    packed = rt.load_gltf(glb, 64, 48, flags=A.GLTF_GLB)
+    assert np.array_equal(packed.tri_verts, plain.tri_verts) and np.array_equal(packed.tri_material, plain.tri_material)
+    assert packed.materials.tobytes() == plain.materials.tobytes()
+    assert all(np.array_equal(packed.camera[k], plain.camera[k]) for k in plain.camera)
+    with pytest.raises(rt.RtError):
+        rt.load_gltf(glb, 64, 48)                                  # the reference's rules: not a JSON text file
+    for cut in (10, 40, os.path.getsize(glb) - 7):                 # truncated containers are rejected, not read past
+        open(str(tmp_path / "cut.glb"), "wb").write(open(glb, "rb").read()[:cut])
+        with pytest.raises(rt.RtError):
+            rt.load_gltf(str(tmp_path / "cut.glb"), 64, 48, flags=A.GLTF_GLB)
+    assert np.array_equal(rt.load_gltf(path, 64, 48, flags=A.GLTF_ALL).tri_verts, plain.tri_verts)
+    # KHR_materials_ior and extras.backgroundColor in a copy of the text file
+    doc = json.load(open(path))
+    glass = [i for i, m in enumerate(doc["materials"]) if m["pbrMetallicRoughness"].get("baseColorFactor", [1, 1, 1, 1])[3] < 1]
+    assert glass
+    doc["materials"][glass[0]].setdefault("extensions", {})["KHR_materials_ior"] = {"ior": 1.33}
+    doc["materials"][0].setdefault("extensions", {})["KHR_materials_ior"] = {}          # the extension's default, 1.5
+    doc["scenes"] = [{"nodes": [0], "extras": {"backgroundColor": [0.25, 0.5, 1.0]}}]
+    doc["scene"] = 0
+    doc["buffers"][0]["uri"] = os.path.basename(path)[:-5] + ".bin"
+    mod = os.path.join(os.path.dirname(path), "cornell_ior_bg.gltf")
+    json.dump(doc, open(mod, "w"))
+    off = rt.load_gltf(mod, 64, 48)
+    assert off.materials.tobytes() == plain.materials.tobytes() and not off.background.any()
+    on = rt.load_gltf(mod, 64, 48, flags=A.GLTF_IOR | A.GLTF_BACKGROUND)
+    assert on.materials["ior"][glass[0]] == np.float32(1.33) and on.materials["ior"][0] == np.float32(1.5)
+    assert np.array_equal(on.background, np.array([0.25, 0.5, 1.0], np.float32))
+    assert np.array_equal(on.tri_verts, plain.tri_verts)
+    assert not rt.load_gltf(mod, 64, 48, flags=A.GLTF_SPEC).background.any()             # not part of the spec set
+    doc["materials"][glass[0]]["extensions"]["KHR_materials_ior"] = {"ior": 0.5}
+    json.dump(doc, open(mod, "w"))
+    with pytest.raises(rt.RtError):
+        rt.load_gltf(mod, 64, 48, flags=A.GLTF_IOR)
