@@ -90,6 +90,25 @@ typedef struct rt_material {
     float ior;    /* always 1.5 from the loader (main.cpp:65) */
 } rt_material;
 
+/* Analytic primitives: Primitive + Plane / Ellipsoid / Box (main.cpp:199-464).  The reference's loader
+ * never constructs them (it emits triangles only, main.cpp:1089), so scene files cannot describe them;
+ * they enter through rt_scene_desc.  Their intersectPrimitive arithmetic is reproduced; they are shaded
+ * like triangles with the material they name, which must not emit (the light list, main.cpp:1096-1098,
+ * holds triangles only here: sampling and pdf of emissive analytic primitives are not built).  In the
+ * closest-hit results primitive k has id ntri + k.  At most RT_MAX_PRIMITIVES per scene: they are tested one
+ * by one after the walk through the triangle tree, as the reference tests planes at its root (552-558). */
+#define RT_PRIM_PLANE 0     /* param = normal (local space; need not be unit length), main.cpp:242-276 */
+#define RT_PRIM_ELLIPSOID 1 /* param = radius per axis, main.cpp:278-365 */
+#define RT_PRIM_BOX 2       /* param = half extent per axis ("size" as intersectPrimitive uses it, 374-375) */
+#define RT_MAX_PRIMITIVES 256u
+typedef struct rt_primitive {
+    int32_t type;      /* RT_PRIM_* */
+    float position[3]; /* Primitive::position */
+    float rotation[4]; /* Primitive::rotation, unit quaternion x, y, z, w; conjRotation is derived */
+    float param[3];
+    uint32_t material;
+} rt_primitive;
+
 /* The flattened InputData (main.cpp:689-706) handed across the boundary: a triangle soup in
  * loader emission order (that order defines the primitive ids returned by the trace calls),
  * one material index per triangle, the material table and the camera.  The light list
@@ -104,6 +123,8 @@ typedef struct rt_scene_desc {
     /* InputData::backgroundColor (main.cpp:694): what applyLight returns for a ray that hits nothing
      * (main.cpp:1190-1192).  The reference never sets it: (0, 0, 0) reproduces it. */
     float background[3];
+    const rt_primitive *prims; /* nprim analytic primitives, may be NULL when nprim == 0 */
+    uint32_t nprim;
 } rt_scene_desc;
 
 typedef struct rt_scene rt_scene;           /* device-resident scene */
@@ -121,7 +142,7 @@ typedef struct rt_scene_stats {
      * (median split).  0 = the bound cost nothing; large values mean a deeper, worse tree than the
      * heuristic wanted, i.e. the scene is close to the triangle limit. */
     uint32_t height_capped_splits;
-    uint32_t reserved_;
+    uint32_t nprims; /* analytic primitives */
 } rt_scene_stats;
 
 /* Counters accumulated on the device by the launches since the last rt_counters_reset:

@@ -247,6 +247,97 @@ struct Triangle {  // main.cpp:466-537
     }
 };
 
+// Primitive + Plane / Ellipsoid / Box, main.cpp:199-464: the reference's loader never constructs them
+// (main.cpp:1089 emits triangles only); restated for hosts that hand them in through the scene description.
+// quat = glm::quat (members x, y, z, w); operator* is glm's quat * vec3.
+struct quat {
+    float x = 0.f, y = 0.f, z = 0.f, w = 1.f;
+};
+inline vec3 operator*(quat q, vec3 v) {
+    vec3 qv = V(q.x, q.y, q.z);
+    vec3 uv = cross(qv, v);
+    vec3 uuv = cross(qv, uv);
+    return v + ((uv * q.w) + uuv) * 2.f;
+}
+
+enum { PRIM_PLANE = 0, PRIM_ELLIPSOID = 1, PRIM_BOX = 2 };
+
+struct Analytic {
+    int type = PRIM_PLANE;
+    vec3 position{0.f, 0.f, 0.f};
+    quat rotation, conjRotation;
+    vec3 param{0.f, 0.f, 1.f};          // Plane::normal / Ellipsoid::radius / Box::size
+    vec3 rotatedNormal{0.f, 0.f, 1.f};  // Plane::update, main.cpp:274-276
+    vec3 radiusSq{1.f, 1.f, 1.f};       // Ellipsoid: radius squared (the reference leaves setting it to its loader)
+    uint32_t material = 0;
+
+    void update() {
+        conjRotation = quat{-rotation.x, -rotation.y, -rotation.z, rotation.w};
+        rotatedNormal = rotation * param;
+        radiusSq = param * param;
+    }
+
+    Intersection intersectPrimitive(vec3 o, vec3 d, int32_t self) const {
+        vec3 no = conjRotation * (o - position);
+        vec3 nd = conjRotation * d;
+        Intersection it;
+        if (type == PRIM_PLANE) {  // main.cpp:246-260
+            it.normal = rotatedNormal;
+            it.t = -dot(no, param) / dot(nd, param);
+            it.isIntersected = it.t > 0.f;
+            if (!it.isIntersected) it.t = INF;
+            it.update(o, d, self);
+            return it;
+        }
+        if (type == PRIM_ELLIPSOID) {  // main.cpp:282-317
+            vec3 ndr = nd / param;
+            vec3 nor = no / param;
+            float a = dot(ndr, ndr);
+            float b = dot(nor, ndr) / a;
+            float c = (dot(nor, nor) - 1) / a;
+            float discr = b * b - c;
+            if (discr < 0.f) return it;
+            float sqrtDiscr = std::sqrt(discr);
+            float mind = -b - sqrtDiscr;
+            float maxd = -b + sqrtDiscr;
+            if (mind < 0.f && maxd > 0.f) {
+                it.t = maxd;
+                it.normal = normalize(rotation * ((no + maxd * nd) / radiusSq)) * -1.f;
+                it.isInside = true;
+                it.isIntersected = true;
+            } else if (mind > 0.f) {
+                it.t = mind;
+                it.normal = normalize(rotation * ((no + mind * nd) / radiusSq));
+                it.isIntersected = true;
+            }
+            it.update(o, d, self);
+            return it;
+        }
+        // Box, main.cpp:370-419
+        vec3 t1 = (param - no) / nd;
+        vec3 t2 = (param * -1.f - no) / nd;
+        float d1 = std::max(std::max(std::min(t1.x, t2.x), std::min(t1.y, t2.y)), std::min(t1.z, t2.z));
+        float d2 = std::min(std::min(std::max(t1.x, t2.x), std::max(t1.y, t2.y)), std::max(t1.z, t2.z));
+        if (d1 > d2 || d2 < 0.f) return it;
+        it.isIntersected = true;
+        if (d1 < 0.f) {
+            it.t = d2;
+            it.isInside = true;
+        } else {
+            it.t = d1;
+        }
+        vec3 ps = (no + it.t * nd) / param;
+        vec3 aps = V(std::fabs(ps.x), std::fabs(ps.y), std::fabs(ps.z));
+        if (aps.x > aps.y && aps.x > aps.z) it.normal = V(ps.x < 0 ? -1.f : 1.f, 0.f, 0.f);
+        else if (aps.y > aps.x && aps.y > aps.z) it.normal = V(0.f, ps.y < 0 ? -1.f : 1.f, 0.f);
+        else it.normal = V(0.f, 0.f, ps.z < 0 ? -1.f : 1.f);
+        it.normal = rotation * it.normal;
+        if (it.isInside) it.normal = it.normal * -1.f;
+        it.update(o, d, self);
+        return it;
+    }
+};
+
 struct BVHNode {  // main.cpp:539-546, ids widened to 32 bits
     AABB aabb;
     uint32_t left = 0, right = 0, firstPrimitiveId = 0, primitiveCount = 0;
@@ -277,8 +368,13 @@ struct Scene {  // main.cpp:689-706 (InputData), minus width/height/samples whic
     std::vector<Triangle> tris;    // re-ordered by the build, like InputData::primitives
     std::vector<int32_t> lights;   // indices into tris, in emission order (main.cpp:1096-1098)
     std::vector<Material> mats;
+    std::vector<Analytic> prims;   // Intersection::primitive of analytic primitive k is -2 - k
     std::vector<BVHNode> nodes;
     Camera cam;
+    // material of whatever an Intersection names
+    const Material &materialOf(int32_t primitive) const {
+        return mats[primitive >= 0 ? tris[primitive].material : prims[-2 - primitive].material];
+    }
     vec3 backgroundColor{0.f, 0.f, 0.f};  // never set by the loader (main.cpp:694)
     uint64_t unsplittable_nodes = 0;
     uint32_t max_depth_seen = 0;
@@ -428,12 +524,25 @@ Intersection bvhIntersectRef(const Scene &s, vec3 o, vec3 d, uint32_t curNode, f
     return closest;
 }
 
+// Analytic primitives are tested one by one (the reference tests its planes at the root of the walk,
+// main.cpp:552-558, 564-570; its boxes' tree boxes are half the size its intersection uses, 374-375 vs
+// 459-460, so walking them through a tree would lose hits).  Strict minimum, list order, and like a
+// triangle's a hit needs t < INF.
+inline void foldAnalytic(const Scene &s, vec3 o, vec3 d, Intersection &closest) {
+    for (size_t k = 0; k < s.prims.size(); ++k) {
+        Intersection ni = s.prims[k].intersectPrimitive(o, d, -2 - (int32_t)k);
+        if (ni.isIntersected && ni.t < INF && (!closest.isIntersected || ni.t < closest.t)) closest = ni;
+    }
+}
+
 // main.cpp:1113-1115
 inline Intersection intersectScene(const Scene &s, vec3 o, vec3 d, Counters &c) {
     bool tie = false;
     float tie_t = 0.f;
     ++c.segments;
-    return bvhIntersectRef(s, o, d, 0, INF, c, tie, tie_t);
+    Intersection closest = bvhIntersectRef(s, o, d, 0, INF, c, tie, tie_t);
+    foldAnalytic(s, o, d, closest);
+    return closest;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -480,7 +589,7 @@ vec3 getReflectedLight(const Scene &s, const Intersection &it, uint32_t rayDepth
 
 // main.cpp:1128-1141
 vec3 applyLightDiffuser(const Scene &s, const Intersection &it, uint32_t rayDepth, Rng &rng, Counters &c) {
-    const Material &m = s.mats[s.tris[it.primitive].material];
+    const Material &m = s.materialOf(it.primitive);
     vec3 x = it.pPlusNormalEps, n = it.normal;
     // Mix::sample, main.cpp:793-800
     bool pickCos = sampleUniform(rng) < 0.5f;
@@ -496,14 +605,14 @@ vec3 applyLightDiffuser(const Scene &s, const Intersection &it, uint32_t rayDept
 
 // main.cpp:1143-1147
 vec3 applyLightMetallic(const Scene &s, const Intersection &it, uint32_t rayDepth, Rng &rng, Counters &c) {
-    const Material &m = s.mats[s.tris[it.primitive].material];
+    const Material &m = s.materialOf(it.primitive);
     vec3 reflected = getReflectedLight(s, it, rayDepth, rng, c);
     return m.color * reflected + m.emission;
 }
 
 // main.cpp:1149-1186
 vec3 applyLightDielectric(const Scene &s, const Intersection &it, uint32_t rayDepth, Rng &rng, Counters &c) {
-    const Material &m = s.mats[s.tris[it.primitive].material];
+    const Material &m = s.materialOf(it.primitive);
     float n1 = 1.f, n2 = m.ior;
     if (it.isInside) {
         n1 = n2;
@@ -534,7 +643,7 @@ vec3 applyLight(const Scene &s, const Intersection &it, uint32_t rayDepth, Rng &
     if (!it.isIntersected) return s.backgroundColor;
     vec3 color = V(0.f, 0.f, 0.f);
     if (rayDepth == 0) return color;
-    const Material &m = s.mats[s.tris[it.primitive].material];
+    const Material &m = s.materialOf(it.primitive);
     if (rayDepth == 1) return m.emission;
     if (m.type == MAT_DIFFUSER) color = applyLightDiffuser(s, it, rayDepth, rng, c);
     else if (m.type == MAT_METALLIC) color = applyLightMetallic(s, it, rayDepth, rng, c);
@@ -693,7 +802,10 @@ void orc_intersect_rays(void *h, uint64_t n, const float *o, const float *d, uin
                     if (ni.isIntersected && (!it.isIntersected || ni.t < it.t)) it = ni;
                 }
             }
-            prim_id[i] = it.isIntersected ? s->tris[it.primitive].origId : 0xFFFFFFFFu;
+            foldAnalytic(*s, ro, rd, it);
+            prim_id[i] = !it.isIntersected ? 0xFFFFFFFFu
+                         : it.primitive >= 0 ? s->tris[it.primitive].origId
+                                             : (uint32_t)s->tris.size() + (uint32_t)(-2 - it.primitive);
             t[i] = it.t;
             if (tie) tie[i] = (tf && it.isIntersected && tt == it.t) ? 1 : 0;
         }
@@ -803,6 +915,29 @@ void orc_tonemap(const float *radiance_sum, uint64_t npixels, uint32_t spp, floa
 // InputData::backgroundColor (main.cpp:694): the reference never sets it; a host that does (an opt-in
 // of the build under test) is checked against applyLight's miss branch (main.cpp:1190-1192) with it.
 void orc_scene_set_background(void *h, float r, float g, float b) { asScene(h)->backgroundColor = V(r, g, b); }
+
+// Analytic primitives: n records of {int32 type; float position[3]; float rotation[4] (x, y, z, w);
+// float param[3]; uint32 material}.
+struct orc_primitive {
+    int32_t type;
+    float position[3];
+    float rotation[4];
+    float param[3];
+    uint32_t material;
+};
+void orc_scene_set_primitives(void *h, const orc_primitive *p, uint32_t n) {
+    Scene *s = asScene(h);
+    s->prims.resize(n);
+    for (uint32_t k = 0; k < n; ++k) {
+        Analytic &a = s->prims[k];
+        a.type = p[k].type;
+        a.position = V(p[k].position[0], p[k].position[1], p[k].position[2]);
+        a.rotation = quat{p[k].rotation[0], p[k].rotation[1], p[k].rotation[2], p[k].rotation[3]};
+        a.param = V(p[k].param[0], p[k].param[1], p[k].param[2]);
+        a.material = p[k].material;
+        a.update();
+    }
+}
 
 // Known-answer probe of the RNG layer (main.cpp:98-111), each group from a freshly seeded engine.
 // raw[4], uni[3], nrm[3], nrm_draws[1] (engine draws used by the 3 normals), ui2[4] =

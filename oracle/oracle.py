@@ -28,6 +28,8 @@ class Material(C.Structure):
 
 
 MATERIAL_DTYPE = np.dtype([("color", "<f4", 3), ("emission", "<f4", 3), ("type", "<i4"), ("ior", "<f4")])
+PRIMITIVE_DTYPE = np.dtype([("type", "<i4"), ("position", "<f4", 3), ("rotation", "<f4", 4), ("param", "<f4", 3),
+                            ("material", "<u4")])
 
 
 def build(force=False):
@@ -52,6 +54,7 @@ def lib():
                                        C.POINTER(Camera)]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_scene_set_background.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L.orc_scene_set_primitives.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.orc_scene_info.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_intersect_rays.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -87,7 +90,7 @@ class OracleScene:
     camera: dict(position, right, up, forward, tan_x, tan_y).
     """
 
-    def __init__(self, tri_verts, tri_material, materials, camera, background=None):
+    def __init__(self, tri_verts, tri_material, materials, camera, background=None, prims=None):
         tv = np.ascontiguousarray(tri_verts, dtype=np.float32).reshape(-1, 9)
         tm = np.ascontiguousarray(tri_material, dtype=np.uint32)
         mats = np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE)
@@ -101,6 +104,9 @@ class OracleScene:
         self._h = lib().orc_scene_create(_p(tv), _p(tm), self.ntri, _p(mats), mats.shape[0], C.byref(cam))
         if background is not None:
             lib().orc_scene_set_background(self._h, *[float(x) for x in background])
+        if prims is not None and len(prims):
+            pr = np.ascontiguousarray(prims, dtype=PRIMITIVE_DTYPE)
+            lib().orc_scene_set_primitives(self._h, _p(pr), pr.shape[0])
 
     def close(self):
         if self._h:

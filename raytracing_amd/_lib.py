@@ -29,13 +29,14 @@ class Material(C.Structure):
 
 class SceneDesc(C.Structure):
     _fields_ = [("tri_verts", C.c_void_p), ("tri_material", C.c_void_p), ("ntri", C.c_uint32),
-                ("materials", C.c_void_p), ("nmat", C.c_uint32), ("camera", Camera), ("background", C.c_float * 3)]
+                ("materials", C.c_void_p), ("nmat", C.c_uint32), ("camera", Camera), ("background", C.c_float * 3),
+                ("prims", C.c_void_p), ("nprim", C.c_uint32)]
 
 
 class SceneStats(C.Structure):
     _fields_ = [("ntri", C.c_uint32), ("nlights", C.c_uint32), ("nnodes", C.c_uint32), ("tree_height", C.c_uint32),
                 ("build_seconds", C.c_double), ("device_bytes", C.c_uint64), ("height_capped_splits", C.c_uint32),
-                ("reserved_", C.c_uint32)]
+                ("nprims", C.c_uint32)]
 
 
 class Counters(C.Structure):

@@ -15,6 +15,11 @@ from . import _lib
 from ._lib import (PIPE_MEGAKERNEL, PIPE_WAVEFRONT, RNG_COUNTER, RNG_REFERENCE, MISS_ID, INF, RtError, check)
 
 MATERIAL_DTYPE = np.dtype([("color", "<f4", 3), ("emission", "<f4", 3), ("type", "<i4"), ("ior", "<f4")])
+# rt_primitive: Plane / Ellipsoid / Box of main.cpp:242-464 (type 0 / 1 / 2; rotation = unit quaternion x, y, z, w;
+# param = plane normal / ellipsoid radii / box half extents)
+PRIMITIVE_DTYPE = np.dtype([("type", "<i4"), ("position", "<f4", 3), ("rotation", "<f4", 4), ("param", "<f4", 3),
+                            ("material", "<u4")])
+PRIM_PLANE, PRIM_ELLIPSOID, PRIM_BOX = 0, 1, 2
 
 
 def _p(a):
@@ -32,8 +37,9 @@ def _stream_ptr(stream):
 class HostScene:
     """A parsed scene file on the host: triangle soup, materials, camera (InputData's host half)."""
 
-    def __init__(self, tri_verts, tri_material, materials, camera, background=(0.0, 0.0, 0.0)):
+    def __init__(self, tri_verts, tri_material, materials, camera, background=(0.0, 0.0, 0.0), prims=None):
         self.background = np.asarray(background, dtype=np.float32).reshape(3)  # InputData::backgroundColor, main.cpp:694
+        self.prims = np.ascontiguousarray(prims if prims is not None else np.zeros(0, PRIMITIVE_DTYPE), dtype=PRIMITIVE_DTYPE)
         self.tri_verts = np.ascontiguousarray(tri_verts, dtype=np.float32).reshape(-1, 3, 3)
         self.tri_material = np.ascontiguousarray(tri_material, dtype=np.uint32)
         self.materials = np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE)
@@ -42,7 +48,7 @@ class HostScene:
 
     def as_dict(self):
         return dict(tri_verts=self.tri_verts, tri_material=self.tri_material, materials=self.materials,
-                    camera=self.camera, background=self.background)
+                    camera=self.camera, background=self.background, prims=self.prims)
 
     def _desc(self):
         d = _lib.SceneDesc()
@@ -56,6 +62,8 @@ class HostScene:
         d.camera.tan_x = float(self.camera["tan_x"])
         d.camera.tan_y = float(self.camera["tan_y"])
         d.background[:] = [float(x) for x in self.background]
+        d.prims = self.prims.ctypes.data if self.prims.size else None
+        d.nprim = self.prims.shape[0]
         return d
 
 
@@ -166,7 +174,7 @@ class Scene:
         check(_lib.lib().rt_scene_get_stats(self._h, C.byref(s)))
         return dict(ntri=s.ntri, nlights=s.nlights, nnodes=s.nnodes, tree_height=s.tree_height,
                     build_seconds=s.build_seconds, device_bytes=int(s.device_bytes),
-                    height_capped_splits=s.height_capped_splits)
+                    height_capped_splits=s.height_capped_splits, nprims=s.nprims)
 
     def flat(self):
         st = self.stats()

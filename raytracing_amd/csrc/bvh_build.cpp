@@ -399,6 +399,37 @@ void build_flat_scene(const rt_scene_desc &desc, FlatScene &out) {
     for (size_t i = 0; i < (size_t)n * 9; ++i)
         if (!std::isfinite(desc.tri_verts[i])) throw std::runtime_error("non-finite vertex coordinate");
 
+    // Analytic primitives (main.cpp:242-464): checked and packed; they stay outside the tree.
+    if (desc.nprim > RT_MAX_PRIMITIVES) throw std::runtime_error("too many analytic primitives (limit " + std::to_string(RT_MAX_PRIMITIVES) + ")");
+    if (desc.nprim && !desc.prims) throw std::runtime_error("null primitive array");
+    out.nprims = desc.nprim;
+    out.prims.assign((size_t)std::max<uint32_t>(desc.nprim, 1) * 12, 0.f);
+    for (uint32_t k = 0; k < desc.nprim; ++k) {
+        const rt_primitive &p = desc.prims[k];
+        if (p.type != RT_PRIM_PLANE && p.type != RT_PRIM_ELLIPSOID && p.type != RT_PRIM_BOX)
+            throw std::runtime_error("analytic primitive type must be RT_PRIM_PLANE, _ELLIPSOID or _BOX");
+        if (p.material >= desc.nmat) throw std::runtime_error("analytic primitive names a missing material");
+        const rt_material &m = desc.materials[p.material];
+        if (hm::length(hm::V3(m.emission[0], m.emission[1], m.emission[2])) > EPS)
+            throw std::runtime_error("analytic primitives must not emit: lights are triangles");
+        float q2 = 0.f, n2 = 0.f;
+        for (int a = 0; a < 4; ++a) {
+            if (!std::isfinite(p.rotation[a])) throw std::runtime_error("non-finite primitive rotation");
+            q2 += p.rotation[a] * p.rotation[a];
+        }
+        if (std::fabs(q2 - 1.f) > 1.0e-3f) throw std::runtime_error("primitive rotation must be a unit quaternion");
+        for (int a = 0; a < 3; ++a) {
+            if (!std::isfinite(p.position[a]) || !std::isfinite(p.param[a])) throw std::runtime_error("non-finite primitive coordinate");
+            if (p.type != RT_PRIM_PLANE && !(p.param[a] > 0.f)) throw std::runtime_error("ellipsoid radii and box extents must be positive");
+            n2 += p.param[a] * p.param[a];
+        }
+        if (p.type == RT_PRIM_PLANE && !(n2 > 0.f)) throw std::runtime_error("plane normal must not be zero");
+        float *q = &out.prims[(size_t)k * 12];
+        q[0] = p.position[0]; q[1] = p.position[1]; q[2] = p.position[2]; q[3] = bits_to_float((uint32_t)p.type);
+        q[4] = p.rotation[0]; q[5] = p.rotation[1]; q[6] = p.rotation[2]; q[7] = p.rotation[3];
+        q[8] = p.param[0]; q[9] = p.param[1]; q[10] = p.param[2]; q[11] = bits_to_float(p.material);
+    }
+
     FlatTree tree;
     build_tree(desc.tri_verts, nullptr, n, tree);
     out.nnodes = tree.nnodes;

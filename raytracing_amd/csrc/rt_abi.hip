@@ -275,6 +275,8 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
     RT_TRY(dev_alloc(s, &s->d_lnodes, f.light_nodes.size() / 4));
     RT_TRY(dev_alloc(s, &s->d_lrecs, f.light_recs.size() / 4));
     RT_TRY(dev_alloc(s, &s->d_mats, mats.size()));
+    RT_TRY(dev_alloc(s, &s->d_prims, f.prims.size() / 4));
+    RT_TRY(hipMemcpy(s->d_prims, f.prims.data(), f.prims.size() * sizeof(float), hipMemcpyHostToDevice));
     RT_TRY(dev_alloc(s, &s->d_counters, kCounterWords));
     RT_TRY(hipMemcpy(s->d_nodes, f.nodes.data(), f.nodes.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     RT_TRY(hipMemcpy(s->d_tris, f.tris.data(), f.tris.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -300,6 +302,9 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
         v.light_tree = (long)f.lights.size() >= minLights && !f.lights.empty() ? 1u : 0u;
     }
     v.mats = s->d_mats;
+    v.prims = s->d_prims;
+    v.ntri = f.ntri;
+    v.nprims = f.nprims;
     v.counters = s->d_counters;
     v.nlights = (uint32_t)f.lights.size();
     v.nmats = (uint32_t)mats.size();
@@ -340,6 +345,7 @@ void rt_scene_destroy(rt_scene *s) {
     (void)hipFree(s->d_lnodes);
     (void)hipFree(s->d_lrecs);
     (void)hipFree(s->d_mats);
+    (void)hipFree(s->d_prims);
     (void)hipFree(s->d_counters);
     delete s;
 }
@@ -353,7 +359,7 @@ int rt_scene_get_stats(const rt_scene *s, rt_scene_stats *out) {
     out->build_seconds = s->flat->build_seconds;
     out->device_bytes = s->device_bytes;
     out->height_capped_splits = s->flat->capped_splits;
-    out->reserved_ = 0;
+    out->nprims = s->flat->nprims;
     return RT_OK;
 }
 

@@ -121,8 +121,10 @@ struct DevScene {
     const float4 *lrecs;      // 4 x float4 per light in that tree's leaf order; q3 = (bits(light index), bits(leaf position), pdfConst, 0)
     const uint32_t *lights;   // leaf-order positions of the emissive triangles
     const DevMaterial *mats;
+    const float4 *prims;      // 3 x float4 per analytic primitive: (position.xyz, bits(type)), rotation xyzw, (param.xyz, bits(material))
     unsigned long long *counters;  // kCounterShards x kCounterStride; per shard [0] segments [1] nodes [2] tri tests [3] light tests
     uint32_t nlights, nmats;
+    uint32_t ntri, nprims;               // a hit index >= ntri names analytic primitive (index - ntri)
     uint32_t light_tree;                 // nonzero: the launchers pick the kernels whose light_pdf walks lnodes
     float grid_origin[3], grid_cell[3];  // node-box plane = origin + q * cell, q a 16-bit integer
     float lgrid_origin[3], lgrid_cell[3];  // the same for lnodes
@@ -408,6 +410,113 @@ struct Traversal {
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Analytic primitives: Plane, Ellipsoid, Box (main.cpp:242-276, 278-365, 367-464), the intersection
+// arithmetic of their intersectPrimitive restated operation for operation.  The reference's loader
+// never constructs them (main.cpp:1089 makes triangles only); here they enter through the scene
+// description and are tested one by one after the walk through the triangle tree, as the reference
+// tests its planes at the root (main.cpp:552-558, 564-570).  A hit needs t < INF like a triangle's.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ v3 cross(v3 x, v3 y) {  // glm::cross
+    return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
+}
+// glm: quat * vec3 = v + ((uv * q.w) + uuv) * 2 with uv = cross(q.xyz, v), uuv = cross(q.xyz, uv)
+__device__ __forceinline__ v3 quat_rotate(float4 q, v3 v) {
+    const v3 u = mk(q.x, q.y, q.z);
+    const v3 uv = cross(u, v);
+    const v3 uuv = cross(u, uv);
+    return v + ((uv * q.w) + uuv) * 2.f;
+}
+__device__ __forceinline__ v3 vdiv(v3 a, v3 b) { return mk(a.x / b.x, a.y / b.y, a.z / b.z); }
+__device__ __forceinline__ float ref_min(float a, float b) { return (b < a) ? b : a; }  // std::min
+__device__ __forceinline__ float ref_max(float a, float b) { return (a < b) ? b : a; }  // std::max
+
+struct PrimHit {
+    bool hit, inside;
+    float t;
+    v3 normal;  // as Intersection::normal leaves intersectPrimitive
+};
+
+// WANT_NORMAL = false: only hit / t (the closest-hit loop); true: the winner's full record for shading.
+template <bool WANT_NORMAL>
+__device__ __forceinline__ PrimHit prim_intersect(const float4 *rec, v3 o, v3 d) {
+    const float4 q0 = rec[0], rot = rec[1], q2 = rec[2];
+    const int type = __float_as_int(q0.w);
+    const float4 conj = make_float4(-rot.x, -rot.y, -rot.z, rot.w);  // conjRotation
+    const v3 no = quat_rotate(conj, o - mk(q0.x, q0.y, q0.z));
+    const v3 nd = quat_rotate(conj, d);
+    const v3 par = mk(q2.x, q2.y, q2.z);
+    PrimHit h;
+    h.hit = false;
+    h.inside = false;
+    h.t = kInf;
+    h.normal = mk(0.f, 0.f, 0.f);
+    if (type == 0) {  // Plane::intersectPrimitive, main.cpp:246-260
+        const float t = -dot(no, par) / dot(nd, par);
+        h.hit = t > 0.f;
+        h.t = h.hit ? t : kInf;
+        if (WANT_NORMAL) h.normal = quat_rotate(rot, par);  // rotatedNormal, main.cpp:274-276
+    } else if (type == 1) {  // Ellipsoid::intersectPrimitive, main.cpp:282-317
+        const v3 ndr = vdiv(nd, par), nor = vdiv(no, par);
+        const float a = dot(ndr, ndr);
+        const float b = dot(nor, ndr) / a;
+        const float c = (dot(nor, nor) - 1.f) / a;
+        const float discr = b * b - c;
+        if (!(discr < 0.f)) {
+            const float sq = __builtin_sqrtf(discr);
+            const float mind = -b - sq, maxd = -b + sq;
+            if (mind < 0.f && maxd > 0.f) {
+                h.t = maxd;
+                h.inside = true;
+                h.hit = true;
+            } else if (mind > 0.f) {
+                h.t = mind;
+                h.hit = true;
+            }
+            if (WANT_NORMAL && h.hit) {
+                const v3 rsq = par * par;  // radiusSq
+                const v3 g = normalize(quat_rotate(rot, vdiv(no + h.t * nd, rsq)));
+                h.normal = h.inside ? -g : g;
+            }
+        }
+    } else {  // Box::intersectPrimitive, main.cpp:370-419
+        const v3 t1 = vdiv(par - no, nd), t2 = vdiv(-par - no, nd);
+        const float d1 = ref_max(ref_max(ref_min(t1.x, t2.x), ref_min(t1.y, t2.y)), ref_min(t1.z, t2.z));
+        const float d2 = ref_min(ref_min(ref_max(t1.x, t2.x), ref_max(t1.y, t2.y)), ref_max(t1.z, t2.z));
+        if (!(d1 > d2 || d2 < 0.f)) {
+            h.hit = true;
+            if (d1 < 0.f) {
+                h.t = d2;
+                h.inside = true;
+            } else {
+                h.t = d1;
+            }
+            if (WANT_NORMAL) {
+                const v3 ps = vdiv(no + h.t * nd, par);
+                const v3 aps = mk(__builtin_fabsf(ps.x), __builtin_fabsf(ps.y), __builtin_fabsf(ps.z));
+                v3 n;
+                if (aps.x > aps.y && aps.x > aps.z) n = mk(ps.x < 0.f ? -1.f : 1.f, 0.f, 0.f);
+                else if (aps.y > aps.x && aps.y > aps.z) n = mk(0.f, ps.y < 0.f ? -1.f : 1.f, 0.f);
+                else n = mk(0.f, 0.f, ps.z < 0.f ? -1.f : 1.f);
+                n = quat_rotate(rot, n);
+                h.normal = h.inside ? -n : n;
+            }
+        }
+    }
+    return h;
+}
+
+// Folds the analytic primitives into a finished triangle walk: strict minimum, in list order.
+__device__ __forceinline__ void analytic_closest(const DevScene &S, v3 o, v3 d, float &tBest, int &triBest) {
+    for (uint32_t k = 0; k < S.nprims; ++k) {
+        const PrimHit h = prim_intersect<false>(S.prims + 3 * (size_t)k, o, d);
+        if (h.hit && h.t < tBest) {
+            tBest = h.t;
+            triBest = (int)(S.ntri + k);
+        }
+    }
+}
+
 template <bool COUNT>
 __device__ __forceinline__ void closest_hit(const DevScene &S, v3 o, v3 d, int *stack, float &tBest, int &triBest,
                                             TraceStats &st) {
@@ -417,6 +526,7 @@ __device__ __forceinline__ void closest_hit(const DevScene &S, v3 o, v3 d, int *
     while (!T.done()) T.step(S, st);
     tBest = T.tBest;
     triBest = T.triBest;
+    if (S.nprims) analytic_closest(S, o, d, tBest, triBest);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -635,18 +745,31 @@ __device__ __forceinline__ bool sample_vertex(const DevScene &S, const LightCach
         return false;
     }
     if (P.depth == 0) return false;   // main.cpp:1195
-    const float4 *tp = S.tris + 4 * (size_t)tri;
-    const float4 q2 = tp[2], q3 = tp[3];
-    V.mat = __float_as_uint(q3.y);
-    V.op = kOpEmit;
-    if (P.depth == 1) return false;   // main.cpp:1197
+    v3 n;
+    bool inside;
+    if ((uint32_t)tri >= S.ntri) {    // an analytic primitive: its normal and side, recomputed for the winner
+        const float4 *rec = S.prims + 3 * (size_t)((uint32_t)tri - S.ntri);
+        V.mat = __float_as_uint(rec[2].w);
+        V.op = kOpEmit;
+        if (P.depth == 1) return false;
+        const PrimHit h = prim_intersect<true>(rec, P.o, P.d);
+        n = h.normal;
+        inside = h.inside;
+    } else {
+        const float4 *tp = S.tris + 4 * (size_t)tri;
+        const float4 q2 = tp[2], q3 = tp[3];
+        V.mat = __float_as_uint(q3.y);
+        V.op = kOpEmit;
+        if (P.depth == 1) return false;   // main.cpp:1197
+        // Triangle::intersectPrimitive's normal (main.cpp:489-494) for the winning triangle
+        n = normalize(mk(q2.y, q2.z, q2.w));
+        inside = dot(n, P.d) > 0.f;
+        if (inside) n = n * -1.f;
+    }
     const DevMaterial M = material(S, LC, V.mat);
     const int type = __float_as_int(M.a.w);
 
-    // Intersection::update (main.cpp:84-95) for the winning triangle
-    v3 n = normalize(mk(q2.y, q2.z, q2.w));
-    const bool inside = dot(n, P.d) > 0.f;
-    if (inside) n = n * -1.f;
+    // Intersection::update (main.cpp:84-95)
     const float nl = -dot(n, P.d);
     const v3 p = P.o + t * P.d;
     const v3 nEps = n * kEps;

@@ -72,6 +72,10 @@ struct FlatScene {
     float light_grid_cell[3] = {1.f, 1.f, 1.f};
     uint32_t light_nnodes = 0;
     uint32_t light_height = 0;
+    // analytic primitives (main.cpp:242-464), 12 floats each: (position.xyz, bits(type)), rotation xyzw,
+    // (param.xyz, bits(material)); tested one by one after the tree walk
+    std::vector<float> prims;
+    uint32_t nprims = 0;
     uint32_t nnodes = 0;
     uint32_t ntri = 0;
     uint32_t tree_height = 0;

@@ -55,7 +55,9 @@ __device__ __forceinline__ void add_counters(const DevScene &S, uint32_t segs, c
     if (lights) atomicAdd(&c[3], (unsigned long long)lights);
 }
 
+// Primitive id reported to the caller: the loader-order id of a triangle, ntri + k for analytic primitive k.
 __device__ __forceinline__ uint32_t tri_loader_id(const DevScene &S, int tri) {
+    if ((uint32_t)tri >= S.ntri) return (uint32_t)tri;
     return __float_as_uint(S.tris[4 * (size_t)tri + 3].x);
 }
 
@@ -291,6 +293,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
     TraceStats st{0, 0, 0, 0};
     for (;;) {
         if (hasRay && T.done()) {
+            if (S.nprims) analytic_closest(S, T.o, T.d, T.tBest, T.triBest);
             V.hit[qpos] = make_float2(T.tBest, __int_as_float(T.triBest));
             hasRay = false;
             ++segs;

@@ -16,6 +16,7 @@ struct rt_scene {
     uint4 *d_lnodes = nullptr;
     float4 *d_lrecs = nullptr;
     rtd::DevMaterial *d_mats = nullptr;
+    float4 *d_prims = nullptr;  // analytic primitives, 3 x float4 each
     unsigned long long *d_counters = nullptr;
     rt::WavefrontBuffers wf;
     uint32_t *d_replay = nullptr;  // vertex records of the replay kernel, grown to the largest request

@@ -441,3 +441,32 @@ def test_gltf_glb_ior_background_flags(scene_dir, tmp_path):
     json.dump(doc, open(mod, "w"))
     with pytest.raises(rt.RtError):
         rt.load_gltf(mod, 64, 48, flags=A.GLTF_IOR)
+
+
+def test_analytic_primitive_validation(scene_dir):
+    """rt_scene_desc.prims (Plane / Ellipsoid / Box, main.cpp:242-464) is checked on the host before any GPU
+    work: type, unit quaternion, positive radii / extents, a non-zero plane normal, an existing and
+    non-emissive material, at most RT_MAX_PRIMITIVES."""
+    import raytracing_amd as rt
+    base = rt.load_gltf(make_scene(scene_dir, "cornell"), 64, 48)
+    emits = np.linalg.norm(base.materials["emission"], axis=1) > 1e-4
+    dark, bright = int(np.flatnonzero(~emits)[0]), int(np.flatnonzero(emits)[0])
+
+    def build(**change):
+        p = np.zeros(1, dtype=rt.PRIMITIVE_DTYPE)
+        p["type"], p["rotation"], p["param"], p["material"] = rt.PRIM_ELLIPSOID, [0, 0, 0, 1], [1, 2, 3], dark
+        for k, v in change.items():
+            p[k] = v
+        return rt.build_flat(rt.HostScene(base.tri_verts, base.tri_material, base.materials, base.camera, prims=p))
+
+    assert build()["tris"].shape[0] == 36
+    for bad in (dict(type=3), dict(rotation=[0, 0, 0, 2]), dict(param=[1, 0, 1]), dict(param=[1, -1, 1]),
+                dict(type=rt.PRIM_PLANE, param=[0, 0, 0]), dict(material=99), dict(material=bright),
+                dict(position=[np.nan, 0, 0])):
+        with pytest.raises(rt.RtError):
+            build(**bad)
+    many = np.zeros(257, dtype=rt.PRIMITIVE_DTYPE)
+    many["rotation"], many["param"], many["material"] = [0, 0, 0, 1], [0, 1, 0], dark
+    with pytest.raises(rt.RtError) as ei:
+        rt.build_flat(rt.HostScene(base.tri_verts, base.tri_material, base.materials, base.camera, prims=many))
+    assert ei.value.code == -4
