@@ -321,7 +321,8 @@ int rt_counters_read(rt_scene *s, rt_counters *out); /* synchronises the device 
 #define RT_KERNEL_MEGA 4        /* megakernel render */
 #define RT_KERNEL_CLOSEST_HIT 5 /* rt_trace_primary* / rt_intersect_rays* */
 #define RT_KERNEL_TONEMAP 6
-#define RT_KERNEL_KINDS 7
+#define RT_KERNEL_SORT 7        /* wavefront: regrouping a ray queue by the cell of the ray origin (three small kernels) */
+#define RT_KERNEL_KINDS 8
 typedef struct rt_kernel_times {
     double ms[RT_KERNEL_KINDS];
     uint64_t launches[RT_KERNEL_KINDS];

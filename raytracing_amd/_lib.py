@@ -44,11 +44,11 @@ class Counters(C.Structure):
                 ("light_tests", C.c_uint64), ("node_lane_slots", C.c_uint64), ("tri_lane_slots", C.c_uint64)]
 
 
-KERNEL_KINDS = ("extend", "shade", "generate", "accumulate", "mega", "closest_hit", "tonemap")
+KERNEL_KINDS = ("extend", "shade", "generate", "accumulate", "mega", "closest_hit", "tonemap", "sort")
 
 
 class KernelTimes(C.Structure):
-    _fields_ = [("ms", C.c_double * 7), ("launches", C.c_uint64 * 7)]
+    _fields_ = [("ms", C.c_double * len(KERNEL_KINDS)), ("launches", C.c_uint64 * len(KERNEL_KINDS))]  # RT_KERNEL_KINDS
 
 
 # name -> (restype, argtypes); exactly the entry points of include/rt_amd.h

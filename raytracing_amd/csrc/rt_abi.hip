@@ -24,7 +24,7 @@ void set_error(const std::string &msg) { g_error = msg; }
 // Path records, index queues, queue counters and work cursors of the wavefront pipeline for
 // kNoAllocPaths paths in flight, laid out back to back in one array that is part of the library's code
 // object: every GPU the library runs on holds its own copy from the first launch on that GPU until the
-// process ends (151 MB).  Host code must not use the array's name as an address: the address on a
+// process ends (155 MB).  Host code must not use the array's name as an address: the address on a
 // given GPU comes from hipGetSymbolAddress with that GPU current (scratch_of below).
 namespace {
 constexpr uint32_t kNoAllocPaths = RT_NOALLOC_MAX_PIXELS;  // one path per pixel at least
@@ -34,9 +34,11 @@ constexpr size_t kScratchC = kScratchLum + (size_t)kNoAllocPaths * 16;        //
 constexpr size_t kScratchHit = kScratchC + (size_t)kNoAllocPaths * 8;         // float2[paths]
 constexpr size_t kScratchQueue0 = kScratchHit + (size_t)kNoAllocPaths * 8;    // uint32_t[paths]
 constexpr size_t kScratchQueue1 = kScratchQueue0 + (size_t)kNoAllocPaths * 4; // uint32_t[paths]
-constexpr size_t kScratchQcount = kScratchQueue1 + (size_t)kNoAllocPaths * 4; // uint32_t[4], padded to 256 B
+constexpr size_t kScratchBin = kScratchQueue1 + (size_t)kNoAllocPaths * 4;    // uint16_t[paths]
+constexpr size_t kScratchQcount = kScratchBin + (size_t)kNoAllocPaths * 2;    // uint32_t[4], padded to 256 B
 constexpr size_t kScratchCursors = kScratchQcount + 256;                      // uint32_t[kWfCursorWords]
-constexpr size_t kScratchBytes = kScratchCursors + rt::kWfCursorWords * sizeof(uint32_t);
+constexpr size_t kScratchBinHist = kScratchCursors + rt::kWfCursorWords * sizeof(uint32_t);  // uint32_t[kWfBinWords]
+constexpr size_t kScratchBytes = kScratchBinHist + rt::kWfBinWords * sizeof(uint32_t);
 }  // namespace
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 
@@ -119,13 +121,15 @@ void free_wavefront(rt_scene *s) {
     dev_free(s, w.hit, cap);
     dev_free(s, w.queue[0], cap);
     dev_free(s, w.queue[1], cap);
+    dev_free(s, w.bin, cap);
     dev_free(s, w.qcount, (size_t)4);
     dev_free(s, w.cursors, rt::kWfCursorWords);
+    dev_free(s, w.binhist, rt::kWfBinWords);
     w = rt::WavefrontBuffers();
 }
 
 // Path records in flight per wavefront pass: whole frames of samples, up to 64 of them or about 128M
-// paths (72 B each with the queues: 9.7 GB of the 288 GB), never more than the call renders.  The
+// paths (74 B each with the queues: 9.9 GB of the 288 GB), never more than the call renders.  The
 // deeper bounces of a pass keep only a few percent of its paths alive, and every launch pays a ramp
 // and a drain of about one ray's duration, so fewer, larger launches win: 16M -> 3424, 32M -> 3656,
 // 64M -> 3763, 128M -> 3827 Mrays/s on the million-triangle 1080p depth-8 workload (4M: 1588 before
@@ -157,11 +161,15 @@ int ensure_wavefront(rt_scene *s, uint32_t npix, uint32_t slots) {
     RT_HIP(dev_alloc(s, &w.hit, (size_t)cap));
     RT_HIP(dev_alloc(s, &w.queue[0], (size_t)cap));
     RT_HIP(dev_alloc(s, &w.queue[1], (size_t)cap));
+    RT_HIP(dev_alloc(s, &w.bin, (size_t)cap));
+    RT_HIP(dev_alloc(s, &w.binhist, rt::kWfBinWords));
+    RT_HIP(hipMemset(w.binhist, 0, rt::kWfBinWords * sizeof(uint32_t)));
     RT_HIP(dev_alloc(s, &w.qcount, (size_t)4));
     RT_HIP(hipMemset(w.qcount, 0, 4 * sizeof(uint32_t)));
     RT_HIP(dev_alloc(s, &w.cursors, rt::kWfCursorWords));
     RT_HIP(hipMemset(w.cursors, 0, rt::kWfCursorWords * sizeof(uint32_t)));
     w.capacity = cap;
+    w.sort = s->sort_rays;
     return RT_OK;
 }
 
@@ -320,6 +328,14 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
     }
     v.tan_x = desc->camera.tan_x;
     v.tan_y = desc->camera.tan_y;
+    for (int k = 0; k < 3; ++k) v.bin_scale[k] = (float)(1u << rtd::kBinBits) / (65000.f * f.grid_cell[k]);
+    {
+        // Regrouping the later bounces' rays by cell pays when the tree and triangles do not fit an XCD's
+        // 4 MB L2 (a 36-triangle box gains nothing and pays for the sort); RT_WF_SORT=0/1 overrides.
+        const size_t sceneBytes = (f.nodes.size() + f.tris.size()) * 4;
+        s->sort_rays = sceneBytes > (size_t)(4u << 20);
+        if (const char *e = std::getenv("RT_WF_SORT")) s->sort_rays = std::atoi(e) != 0;
+    }
     v.has_background = 0u;
     for (int k = 0; k < 3; ++k) {
         v.background[k] = desc->background[k];
@@ -506,6 +522,9 @@ int rt_render_noalloc_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t
     wb.hit = reinterpret_cast<float2 *>(base + kScratchHit);
     wb.queue[0] = reinterpret_cast<uint32_t *>(base + kScratchQueue0);
     wb.queue[1] = reinterpret_cast<uint32_t *>(base + kScratchQueue1);
+    wb.bin = reinterpret_cast<uint16_t *>(base + kScratchBin);
+    wb.binhist = reinterpret_cast<uint32_t *>(base + kScratchBinHist);
+    wb.sort = s->sort_rays;
     wb.qcount = reinterpret_cast<uint32_t *>(base + kScratchQcount);
     wb.cursors = reinterpret_cast<uint32_t *>(base + kScratchCursors);
     // the array keeps the previous call's contents: counters and cursors start from zero, the records

@@ -132,7 +132,28 @@ struct DevScene {
     float tan_x, tan_y;
     float background[3];  // InputData::backgroundColor (main.cpp:694): radiance of a ray that hits nothing
     uint32_t has_background;  // any component nonzero
+    float bin_scale[3];   // (position - grid_origin) * bin_scale = coordinate in units of one ray-sorting cell
 };
+
+// Ray-sorting cells: the node grid's extent cut into 2^kBinBits cells per axis, numbered in Morton order.
+// The wavefront pipeline groups the rays of a bounce by the cell of their origin, so that the rays in
+// flight at one time walk the same part of the tree and that part stays in L2 (see wf_bin_scatter).
+constexpr uint32_t kBinBits = 4;
+constexpr uint32_t kBins = 1u << (3u * kBinBits);
+__device__ __forceinline__ uint32_t bin_spread(uint32_t v) {  // 4 bits -> every third bit
+    v = (v | (v << 4)) & 0x0C3u;
+    v = (v | (v << 2)) & 0x249u;
+    return v;
+}
+static_assert(kBinBits <= 4, "bin_spread handles 4 bits per axis");
+__device__ __forceinline__ uint32_t ray_bin(const DevScene &S, v3 o) {
+    const float m = (float)((1u << kBinBits) - 1u);
+    // fmaxf(NaN, 0) = 0: a path whose origin went NaN lands in cell 0
+    const uint32_t qx = (uint32_t)__builtin_fminf(__builtin_fmaxf((o.x - S.grid_origin[0]) * S.bin_scale[0], 0.f), m);
+    const uint32_t qy = (uint32_t)__builtin_fminf(__builtin_fmaxf((o.y - S.grid_origin[1]) * S.bin_scale[1], 0.f), m);
+    const uint32_t qz = (uint32_t)__builtin_fminf(__builtin_fmaxf((o.z - S.grid_origin[2]) * S.bin_scale[2], 0.f), m);
+    return bin_spread(qx) | (bin_spread(qy) << 1) | (bin_spread(qz) << 2);
+}
 
 struct TraceStats {
     uint32_t nodes, tris;

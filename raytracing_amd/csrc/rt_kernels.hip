@@ -214,6 +214,8 @@ __global__ __launch_bounds__(kBlock) void k_render_replay(DevScene S, rt::Render
 constexpr uint32_t kShards = 8;           // work cursors of wf_extend (see there)
 constexpr uint32_t kCursorStride = 1024;  // words between cursors
 static_assert(kShards * kCursorStride == rt::kWfCursorWords, "cursor buffer size");
+static_assert(2 * kBins == rt::kWfBinWords, "histogram + cursor buffer size");
+static_assert(kBins % kBlock == 0 && kBins <= 65536, "cells per thread in wf_bin_scan; cells are stored as 16 bits");
 
 // Path i's record is 40 bytes: 32 contiguous ones that hold the ray (what wf_extend reads) and 8 apart; a
 // lane moves it with two 16-byte and one 8-byte access.  It holds what the next bounce needs and nothing else.  The radiance a path has gathered lives apart (it changes
@@ -223,7 +225,8 @@ struct WfView {
     float4 *ray;    // [2i] = (o.xyz, d.x)  [2i+1] = (d.y, d.z, throughput.x, throughput.y)
     float2 *c;      // [i] = (throughput.z, bits(rng))
     float4 *lum;    // [i] = (radiance gathered so far .xyz, 0)
-    float2 *hit;    // [j] = (hit t, bits(hit triangle)) of the ray at POSITION j of the queue being traced
+    float2 *hit;    // [i] = (hit t, bits(hit triangle)) of path i's current ray
+    uint16_t *bin;  // [j] = ray-sorting cell of the ray at position j of the queue wf_shade is filling
     uint32_t cap;
 };
 
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
     const uint32_t lane = threadIdx.x & 63u;
     T.idle();
     T.bind(s_stack + threadIdx.x);
-    uint32_t qpos = 0, segs = 0;  // queue position of this lane's ray: where its hit goes
+    uint32_t slot = 0, segs = 0;  // path slot of this lane's ray: where its hit goes
     bool hasRay = false;
     uint32_t chunkNext = 0, chunkEnd = 0;  // wave-uniform
     uint32_t shard = blockIdx.x % kShards, dry = 0;  // wave-uniform: current shard, shards found empty in a row
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
     for (;;) {
         if (hasRay && T.done()) {
             if (S.nprims) analytic_closest(S, T.o, T.d, T.tBest, T.triBest);
-            V.hit[qpos] = make_float2(T.tBest, __int_as_float(T.triBest));
+            V.hit[slot] = make_float2(T.tBest, __int_as_float(T.triBest));
             hasRay = false;
             ++segs;
         }
@@ -327,8 +330,8 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
                 const uint32_t avail = chunkEnd - chunkNext;
                 const uint32_t take = avail < (uint32_t)nIdle - given ? avail : (uint32_t)nIdle - given;
                 if (!hasRay && rank >= given && rank < given + take) {
-                    qpos = chunkNext + (rank - given);
-                    const uint32_t slot = queue ? queue[qpos] : qpos;
+                    const uint32_t qpos = chunkNext + (rank - given);
+                    slot = queue ? queue[qpos] : qpos;
                     const float4 r0 = V.ray[2 * (size_t)slot], r1 = V.ray[2 * (size_t)slot + 1];
                     T.start(S, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y));
                     hasRay = true;
@@ -356,8 +359,9 @@ template <bool TREE>
 __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const uint32_t *__restrict__ queue,
                                                     const uint32_t *__restrict__ qcount_in,
                                                     uint32_t *__restrict__ queue_out, uint32_t *__restrict__ qcount_out,
-                                                    uint32_t *__restrict__ cursors, uint32_t depth) {
-    __shared__ uint32_t s_buf[kAppendBuf];
+                                                    uint32_t *__restrict__ cursors, uint32_t depth, uint32_t want_bins) {
+    __shared__ uint32_t s_buf[kAppendBuf];  // path slot | ray-sorting cell << 27 would not fit: cells ride in s_bin
+    __shared__ uint16_t s_bin[kAppendBuf];
     __shared__ uint32_t s_count, s_base;
     __shared__ LightCacheStorage s_lights;
     __shared__ int s_stack[TREE ? kStack * kBlock : 1];  // light_pdf's walk of the light tree
@@ -371,29 +375,23 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const u
     // every thread of the workgroup runs the same number of rounds: the barriers below are uniform
     const uint32_t stride = gridDim.x * kBlock;
     const uint32_t rounds = (count + stride - 1u) / stride;
-    // A round's path needs three dependent trips to memory: its queue entry, its record, the triangle it
-    // hit.  The hit lies at the queue POSITION (wf_extend stores it there), so it does not wait for the
-    // queue entry, and both are fetched one round ahead: what a round still waits for is one trip, the
-    // record and the triangle side by side.
+    // The queue entry of a round is fetched one round ahead; the round then waits for one trip to memory:
+    // the path's record and its hit side by side (both live at the path's slot).  `queue` is the order in
+    // which the previous shading pass appended the survivors -- ascending slots within each run -- not
+    // the cell order wf_extend traced them in, so the records stream instead of being gathered.
     uint32_t j = blockIdx.x * kBlock + threadIdx.x;
     uint32_t iNext = 0;
-    float2 hNext = make_float2(0.f, 0.f);
-    if (j < count) {
-        iNext = queue ? queue[j] : j;
-        hNext = V.hit[j];
-    }
+    if (j < count) iNext = queue ? queue[j] : j;
     for (uint32_t r = 0; r < rounds; ++r, j += stride) {
         bool alive = false;
         const uint32_t i = iNext;
-        const float2 h = hNext;
+        uint32_t cell = 0;
         if (j < count) {
+            const float2 h = V.hit[i];
             const float4 r0 = V.ray[2 * (size_t)i], r1 = V.ray[2 * (size_t)i + 1];
             const float2 r2 = V.c[i];
             const uint32_t jn = j + stride;
-            if (jn < count) {
-                iNext = queue ? queue[jn] : jn;
-                hNext = V.hit[jn];
-            }
+            if (jn < count) iNext = queue ? queue[jn] : jn;
             PathState P;
             P.o = mk(r0.x, r0.y, r0.z);
             P.d = mk(r0.w, r1.x, r1.y);
@@ -410,6 +408,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const u
                 V.ray[2 * (size_t)i] = make_float4(P.o.x, P.o.y, P.o.z, P.d.x);
                 V.ray[2 * (size_t)i + 1] = make_float4(P.d.y, P.d.z, P.T.x, P.T.y);
                 V.c[i] = make_float2(P.T.z, __uint_as_float(P.rng));
+                if (want_bins) cell = ray_bin(S, P.o);
             }
         }
         const unsigned long long mask = __ballot(alive);
@@ -418,7 +417,11 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const u
             uint32_t base = 0;
             if (lane == (uint32_t)leader) base = atomicAdd(&s_count, (uint32_t)__builtin_popcountll(mask));
             base = __shfl(base, leader);
-            if (alive) s_buf[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = i;
+            if (alive) {
+                const uint32_t at = base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                s_buf[at] = i;
+                s_bin[at] = (uint16_t)cell;
+            }
         }
         __syncthreads();
         const uint32_t n = s_count;
@@ -427,12 +430,99 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const u
             __syncthreads();
             const uint32_t gbase = s_base;
             for (uint32_t k = threadIdx.x; k < n; k += kBlock) queue_out[gbase + k] = s_buf[k];
+            if (want_bins)
+                for (uint32_t k = threadIdx.x; k < n; k += kBlock) V.bin[gbase + k] = s_bin[k];
             __syncthreads();
             if (threadIdx.x == 0) s_count = 0u;
             __syncthreads();
         }
     }
     if (lightTests) add_counters(S, 0u, TraceStats{0, 0, 0, 0}, lightTests, false);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ray sorting.  From the second bounce on the survivors of a pass are scattered over the whole scene, and
+// rays that are traced at the same time touch unrelated parts of a tree that is far larger than an XCD's
+// L2: the same 47 node visits per ray that cost 0.16 ns at the first bounce cost 0.4 ns at the last.  The
+// queue is therefore regrouped by the cell of the ray origin (ray_bin: 4096 cells in Morton order) before
+// it is traced -- a counting sort in three small kernels, entirely on the device (the queue length never
+// visits the host): histogram of the cells wf_shade wrote next to the queue, exclusive scan, scatter.
+// Only path INDICES move; records stay in their slots.  The order inside a cell is whatever the atomics
+// make it, which no result depends on: every path's arithmetic is its own and sums are taken per slot.
+// Measured on the million-triangle frame (64 samples per pass): wf_extend 70.2 -> 55.2 ms with 4096
+// cells (512: 57.1, 64: 60.6, 8: 65.9; 2^24 cells: 52.7); sorting only inside blocks of 2K to 128K
+// entries gains a fifth of that, so it is the working set per XCD that matters, not the wave.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kSortGrid = 1024;      // workgroups of the histogram and scatter kernels
+constexpr uint32_t kSortFromBounce = 1;   // the rays leaving the first hits still follow the pixel tiles: sorting them gains 1 % of wf_extend
+constexpr uint32_t kSortTile = 4 * kBins;  // entries a workgroup places at a time
+
+__global__ __launch_bounds__(kBlock) void wf_bin_hist(const uint16_t *__restrict__ bin, const uint32_t *__restrict__ qcount,
+                                                       uint32_t *__restrict__ hist) {
+    __shared__ uint32_t s_hist[kBins];
+    const uint32_t count = *qcount;
+    if (blockIdx.x * kBlock >= count) return;  // uniform per workgroup
+    for (uint32_t b = threadIdx.x; b < kBins; b += kBlock) s_hist[b] = 0u;
+    __syncthreads();
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < count; j += gridDim.x * kBlock) atomicAdd(&s_hist[bin[j]], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < kBins; b += kBlock) {
+        const uint32_t c = s_hist[b];
+        if (c) atomicAdd(&hist[b], c);
+    }
+}
+
+// One workgroup: cursor[b] = number of entries in cells below b; clears the histogram for its next use.
+__global__ __launch_bounds__(kBlock) void wf_bin_scan(uint32_t *__restrict__ hist, uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t s_part[kBlock];
+    constexpr uint32_t per = kBins / kBlock;
+    uint32_t v[per], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < per; ++k) {
+        v[k] = hist[threadIdx.x * per + k];
+        hist[threadIdx.x * per + k] = 0u;
+        sum += v[k];
+    }
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < kBlock; off <<= 1) {  // inclusive scan of the per-thread sums
+        const uint32_t add = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = s_part[threadIdx.x] - sum;
+#pragma unroll
+    for (uint32_t k = 0; k < per; ++k) {
+        cursor[threadIdx.x * per + k] = run;
+        run += v[k];
+    }
+}
+
+// queue_out = queue_in regrouped by cell.  A workgroup takes a tile of entries, counts them per cell in LDS,
+// reserves the tile's share of every cell it met with one global atomic per cell, then reads the tile again
+// and hands every entry the next free position of its cell.  (Tiles of 2048 entries with the ranks kept in
+// registers took the same time: neither the global atomics nor the second read is what this kernel waits
+// for, the scattered 4-byte stores are.)
+__global__ __launch_bounds__(kBlock) void wf_bin_scatter(const uint32_t *__restrict__ queue_in, const uint16_t *__restrict__ bin,
+                                                          const uint32_t *__restrict__ qcount, uint32_t *__restrict__ cursor,
+                                                          uint32_t *__restrict__ queue_out) {
+    __shared__ uint32_t s_cell[kBins];  // entries of the tile per cell, then the next free position of the cell
+    const uint32_t count = *qcount;
+    for (uint32_t t0 = blockIdx.x * kSortTile; t0 < count; t0 += gridDim.x * kSortTile) {  // uniform per workgroup
+        const uint32_t t1 = (count - t0 < kSortTile) ? count : t0 + kSortTile;
+        for (uint32_t b = threadIdx.x; b < kBins; b += kBlock) s_cell[b] = 0u;
+        __syncthreads();
+        for (uint32_t j = t0 + threadIdx.x; j < t1; j += kBlock) atomicAdd(&s_cell[bin[j]], 1u);
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < kBins; b += kBlock) {
+            const uint32_t c = s_cell[b];
+            if (c) s_cell[b] = atomicAdd(&cursor[b], c);
+        }
+        __syncthreads();
+        for (uint32_t j = t0 + threadIdx.x; j < t1; j += kBlock) queue_out[atomicAdd(&s_cell[bin[j]], 1u)] = queue_in[j];
+        __syncthreads();
+    }
 }
 
 // radiance_sum[pix] (+)= sum over the batch's sample slots, in slot order (deterministic).
@@ -544,7 +634,7 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
     // `slots` = whole frames of samples in flight per pass; the host guarantees 1 <= slots and
     // slots * npix <= wb.capacity.  A pixel's samples are added in sample order whatever the pass
     // boundaries are (wf_accumulate continues from the stored sum), so the result does not depend on slots.
-    WfView V{wb.ray, wb.c, wb.lum, wb.hit, wb.capacity};
+    WfView V{wb.ray, wb.c, wb.lum, wb.hit, wb.bin, wb.capacity};
     uint32_t done = 0;
     bool first = true;
     while (done < rp.spp_count) {
@@ -559,9 +649,18 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
                            wb.qcount, wb.cursors);
         timer.end(stream);
         const uint32_t bounces = rp.max_depth ? rp.max_depth : 1u;  // depth 0 still traces the camera ray
+        // Two queue buffers.  qu = the one holding this bounce's paths in the order wf_shade appended them
+        // (-1: the identity queue of the camera rays), which is the order wf_shade walks them in; qs = the one
+        // wf_extend traces, the same paths regrouped by cell when the previous bounce sorted.  wf_shade fills
+        // the buffer that is not qu (wf_extend is done with it by then); a sort then writes into qu's buffer,
+        // which nothing reads any more.
+        int qu = -1, qs = -1;
         for (uint32_t b = 0; b < bounces; ++b) {
             const uint32_t in = b & 1u, out = in ^ 1u;
-            const uint32_t *qin = (b == 0) ? nullptr : wb.queue[in];
+            const uint32_t *qin = (qs < 0) ? nullptr : wb.queue[qs];
+            const uint32_t *qshade = (qu < 0) ? nullptr : wb.queue[qu];
+            const int fill = (qu == 0) ? 1 : 0;
+            const bool sort = wb.sort && b >= kSortFromBounce && b + 1 < bounces;
             timer.begin(kKernExtend, stream);
             if (count)
                 hipLaunchKernelGGL(wf_extend<true>, dim3(egrid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in,
@@ -572,8 +671,20 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
             timer.end(stream);
             timer.begin(kKernShade, stream);
             hipLaunchKernelGGL(S.light_tree ? wf_shade<true> : wf_shade<false>, dim3(grid), dim3(kBlock), 0, stream, S, V,
-                               qin, wb.qcount + in, wb.queue[out], wb.qcount + out, wb.cursors, rp.max_depth - (rp.max_depth ? b : 0u));
+                               qshade, wb.qcount + in, wb.queue[fill], wb.qcount + out, wb.cursors,
+                               rp.max_depth - (rp.max_depth ? b : 0u), sort ? 1u : 0u);
             timer.end(stream);
+            qu = qs = fill;
+            if (sort) {
+                const uint32_t sgrid = grid < kSortGrid ? grid : kSortGrid;
+                timer.begin(kKernSort, stream);
+                hipLaunchKernelGGL(wf_bin_hist, dim3(sgrid), dim3(kBlock), 0, stream, wb.bin, wb.qcount + out, wb.binhist);
+                hipLaunchKernelGGL(wf_bin_scan, dim3(1), dim3(kBlock), 0, stream, wb.binhist, wb.binhist + kBins);
+                hipLaunchKernelGGL(wf_bin_scatter, dim3(sgrid), dim3(kBlock), 0, stream, wb.queue[fill], wb.bin, wb.qcount + out,
+                                   wb.binhist + kBins, wb.queue[1 - fill]);
+                timer.end(stream);
+                qs = 1 - fill;
+            }
         }
         const uint32_t agrid = (npix + kBlock - 1) / kBlock < kPersistentBlocks ? (npix + kBlock - 1) / kBlock
                                                                                 : kPersistentBlocks;

@@ -23,6 +23,7 @@ struct rt_scene {
     uint64_t replay_words = 0;
     uint64_t device_bytes = 0;
     bool counting = false;
+    bool sort_rays = false;  // wavefront pipeline: regroup the rays of the later bounces by cell
     uint32_t nmat = 0;
     rt::KernelTimer timer;
     uint64_t host_segments = 0;  // segments of launches whose ray count the host knows (one per ray)
