@@ -275,7 +275,9 @@ __global__ __launch_bounds__(kBlock) void wf_generate(DevScene S, rt::RenderPara
 constexpr uint32_t kChunk = 128;  // 64: -1 %, 256: -2 %, 512: -5 % (million-triangle scene); Cornell flat from 128 up
 constexpr int kRefill = 20;  // 4: -3 %, 12: -1 %, 16 to 24: within 0.5 %, 32: -2 %
 
-template <bool COUNT>
+// PRIMS: the scene holds analytic primitives, folded into every finished walk.  A separate instantiation:
+// with the fold compiled into the one kernel, scenes without primitives traced 12 % slower.
+template <bool COUNT, bool PRIMS>
 __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const uint32_t *__restrict__ queue,
                                                      const uint32_t *__restrict__ qcount_in,
                                                      uint32_t *__restrict__ qcount_zero, uint32_t *__restrict__ cursors) {
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
     TraceStats st{0, 0, 0, 0};
     for (;;) {
         if (hasRay && T.done()) {
-            if (S.nprims) analytic_closest(S, T.o, T.d, T.tBest, T.triBest);
+            if (PRIMS) analytic_closest(S, T.o, T.d, T.tBest, T.triBest);
             V.hit[slot] = make_float2(T.tBest, __int_as_float(T.triBest));
             hasRay = false;
             ++segs;
@@ -355,8 +357,9 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
 // queue with ONE atomic and copies the buffer out with coalesced stores.
 constexpr uint32_t kAppendBuf = 2048;  // LDS entries per workgroup (8 KB); flushed above kAppendBuf - kBlock
 
+// Six waves per SIMD (at most 80 VGPRs): left alone the compiler takes 83 and a wave less; no spills (-2 %).
 template <bool TREE>
-__global__ __launch_bounds__(kBlock) void wf_shade(DevScene S, WfView V, const uint32_t *__restrict__ queue,
+__global__ __launch_bounds__(kBlock, 6) void wf_shade(DevScene S, WfView V, const uint32_t *__restrict__ queue,
                                                     const uint32_t *__restrict__ qcount_in,
                                                     uint32_t *__restrict__ queue_out, uint32_t *__restrict__ qcount_out,
                                                     uint32_t *__restrict__ cursors, uint32_t depth, uint32_t want_bins) {
@@ -662,12 +665,9 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
             const int fill = (qu == 0) ? 1 : 0;
             const bool sort = wb.sort && b >= kSortFromBounce && b + 1 < bounces;
             timer.begin(kKernExtend, stream);
-            if (count)
-                hipLaunchKernelGGL(wf_extend<true>, dim3(egrid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in,
-                                   wb.qcount + out, wb.cursors);
-            else
-                hipLaunchKernelGGL(wf_extend<false>, dim3(egrid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in,
-                                   wb.qcount + out, wb.cursors);
+            auto ext = S.nprims ? (count ? wf_extend<true, true> : wf_extend<false, true>)
+                                : (count ? wf_extend<true, false> : wf_extend<false, false>);
+            hipLaunchKernelGGL(ext, dim3(egrid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in, wb.qcount + out, wb.cursors);
             timer.end(stream);
             timer.begin(kKernShade, stream);
             hipLaunchKernelGGL(S.light_tree ? wf_shade<true> : wf_shade<false>, dim3(grid), dim3(kBlock), 0, stream, S, V,
