@@ -364,6 +364,56 @@ void build_tree(const float *verts, const uint32_t *which, uint32_t n, FlatTree 
     }
 }
 
+// The flattened two-child tree with up to four children per node (layout: rt_internal.h).  Depth-first
+// order: a node is followed by the subtrees of its children.
+struct WideBuilder {
+    const std::vector<uint32_t> &n2;
+    const float *cell;
+    std::vector<uint32_t> out;
+
+    float area(const uint32_t *w) const {
+        float e[3];
+        for (int a = 0; a < 3; ++a) e[a] = (float)((w[a] >> 16) - (w[a] & 0xffffu)) * cell[a];
+        return e[0] * e[1] + e[0] * e[2] + e[1] * e[2];
+    }
+    // returns the wide index of two-child node `id`
+    uint32_t emit(uint32_t id) {
+        uint32_t box[4][3];
+        int32_t ref[4];
+        int n = 2;
+        for (int c = 0; c < 2; ++c) {
+            std::memcpy(box[c], &n2[(size_t)id * 8 + 3 * c], 12);
+            ref[c] = (int32_t)n2[(size_t)id * 8 + 6 + c];
+        }
+        while (n < 4) {
+            int best = -1;
+            float bestA = -1.f;
+            for (int c = 0; c < n; ++c) {
+                if (ref[c] < 0) continue;
+                const float a = area(box[c]);
+                if (a > bestA) bestA = a, best = c;
+            }
+            if (best < 0) break;
+            const uint32_t y = (uint32_t)ref[best];
+            std::memcpy(box[best], &n2[(size_t)y * 8], 12);
+            ref[best] = (int32_t)n2[(size_t)y * 8 + 6];
+            std::memcpy(box[n], &n2[(size_t)y * 8 + 3], 12);
+            ref[n] = (int32_t)n2[(size_t)y * 8 + 7];
+            ++n;
+        }
+        const uint32_t me = (uint32_t)(out.size() / 16);
+        out.resize(out.size() + 16);
+        for (int c = 0; c < 4; ++c)
+            for (int a = 0; a < 3; ++a) out[(size_t)me * 16 + 3 * c + a] = c < n ? box[c][a] : 0x0000FFFFu;
+        for (int c = 0; c < 4; ++c) {
+            uint32_t r = 0x7FFFFFFFu;
+            if (c < n) r = ref[c] < 0 ? (uint32_t)ref[c] : emit((uint32_t)ref[c]);
+            out[(size_t)me * 16 + 12 + c] = r;
+        }
+        return me;
+    }
+};
+
 // Triangle record (16 floats) of loader triangle `id`: Triangle::update (main.cpp:527-536).
 void triangle_record(const rt_scene_desc &desc, uint32_t id, float *q) {
     const float *v = desc.tri_verts + 9 * (size_t)id;
@@ -442,6 +492,13 @@ void build_flat_scene(const rt_scene_desc &desc, FlatScene &out) {
     for (int a = 0; a < 3; ++a) {
         out.grid_origin[a] = tree.grid_origin[a];
         out.grid_cell[a] = tree.grid_cell[a];
+    }
+    {
+        WideBuilder wb{out.nodes, out.grid_cell, {}};
+        wb.out.reserve((size_t)out.nnodes * 10);
+        wb.emit(0);
+        out.wide.swap(wb.out);
+        out.nwide = (uint32_t)(out.wide.size() / 16);
     }
 
     // Triangles in leaf order, with the derived data of Triangle::update (main.cpp:527-536).

@@ -467,6 +467,8 @@ int rt_host_scene_get_desc(const rt_host_scene *hs, rt_scene_desc *out) {
     out->nmat = (uint32_t)hs->materials.size();
     out->camera = hs->camera;
     for (int k = 0; k < 3; ++k) out->background[k] = hs->background[k];
+    out->prims = nullptr;  // scene files cannot describe analytic primitives
+    out->nprim = 0;
     return RT_OK;
 }
 

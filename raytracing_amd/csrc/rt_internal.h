@@ -58,8 +58,20 @@ struct FlatTree {
     double sah_nodes = 0.0, sah_tris = 0.0;  // surface-area estimate of node visits / triangle tests per random ray
 };
 
+// Wide node (64 B = 4 x 16 B), the same tree with up to four children per node: a node's larger inner
+// children are replaced by their own two children (largest box first) until four are reached, boxes copied
+// word for word from the two-child nodes.
+//   w0..w2 = box of child 0 (x, y, z words as above), w3..w5 = child 1, w6..w8 = child 2, w9..w11 = child 3
+//   w12..w15 = child references: >= 0 index of a wide node, < 0 a leaf as above
+// An unused child has the inverted box lo = 65535, hi = 0 on every axis (no ray crosses it) and the
+// reference 0x7FFFFFFF.  wf_extend walks this tree: half the node visits of the two-child one for the same
+// box tests, and the vector-memory path charges per visit (a first touch of a line) and per load instruction.
+// Walking it can need more stack than the two-child tree guarantees (three pushes per visit); a ray that
+// runs out is traced again on the two-child tree.
 struct FlatScene {
     std::vector<uint32_t> nodes;    // nnodes * 8
+    std::vector<uint32_t> wide;     // nwide * 16
+    uint32_t nwide = 0;
     float grid_origin[3] = {0.f, 0.f, 0.f};
     float grid_cell[3] = {1.f, 1.f, 1.f};
     std::vector<float> tris;        // ntri * 16

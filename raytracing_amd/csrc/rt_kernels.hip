@@ -358,8 +358,9 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
 constexpr uint32_t kAppendBuf = 2048;  // LDS entries per workgroup (8 KB); flushed above kAppendBuf - kBlock
 
 // Six waves per SIMD (at most 80 VGPRs): left alone the compiler takes 83 and a wave less; no spills (-2 %).
+// (Not the light-tree variant: its stack in LDS bounds it to fewer waves anyway.)
 template <bool TREE>
-__global__ __launch_bounds__(kBlock, 6) void wf_shade(DevScene S, WfView V, const uint32_t *__restrict__ queue,
+__global__ __launch_bounds__(kBlock, TREE ? 1 : 6) void wf_shade(DevScene S, WfView V, const uint32_t *__restrict__ queue,
                                                     const uint32_t *__restrict__ qcount_in,
                                                     uint32_t *__restrict__ queue_out, uint32_t *__restrict__ qcount_out,
                                                     uint32_t *__restrict__ cursors, uint32_t depth, uint32_t want_bins) {
