@@ -401,14 +401,38 @@ struct WideBuilder {
             ref[n] = (int32_t)n2[(size_t)y * 8 + 7];
             ++n;
         }
-        const uint32_t me = (uint32_t)(out.size() / 16);
-        out.resize(out.size() + 16);
-        for (int c = 0; c < 4; ++c)
-            for (int a = 0; a < 3; ++a) out[(size_t)me * 16 + 3 * c + a] = c < n ? box[c][a] : 0x0000FFFFu;
+        const uint32_t me = (uint32_t)(out.size() / 12);
+        out.resize(out.size() + 12);
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t org[3], shift[3];
+        for (int a = 0; a < 3; ++a) {
+            uint32_t lo = 65535u, hi = 0u;
+            for (int c = 0; c < n; ++c) {
+                lo = std::min(lo, box[c][a] & 0xffffu);
+                hi = std::max(hi, box[c][a] >> 16);
+            }
+            uint32_t s = 0;
+            while (((hi - lo + (1u << s) - 1u) >> s) > 255u) ++s;
+            org[a] = lo;
+            shift[a] = s;
+            for (int c = 0; c < 4; ++c) {
+                uint32_t ql = 255u, qh = 0u;  // an unused child: inverted (and masked by the child count)
+                if (c < n) {
+                    ql = ((box[c][a] & 0xffffu) - lo) >> s;
+                    qh = ((box[c][a] >> 16) - lo + (1u << s) - 1u) >> s;
+                    if (qh > 255u || ql > qh) throw std::runtime_error("internal: wide node quantisation");
+                }
+                w[2 * a] |= ql << (8 * c);
+                w[2 * a + 1] |= qh << (8 * c);
+            }
+        }
+        w[6] = org[0] | (org[1] << 16);
+        w[7] = org[2] | (shift[0] << 16) | (shift[1] << 20) | (shift[2] << 24) | ((uint32_t)n << 28);
+        for (int k = 0; k < 8; ++k) out[(size_t)me * 12 + k] = w[k];
         for (int c = 0; c < 4; ++c) {
             uint32_t r = 0x7FFFFFFFu;
             if (c < n) r = ref[c] < 0 ? (uint32_t)ref[c] : emit((uint32_t)ref[c]);
-            out[(size_t)me * 16 + 12 + c] = r;
+            out[(size_t)me * 12 + 8 + c] = r;
         }
         return me;
     }
@@ -498,7 +522,7 @@ void build_flat_scene(const rt_scene_desc &desc, FlatScene &out) {
         wb.out.reserve((size_t)out.nnodes * 10);
         wb.emit(0);
         out.wide.swap(wb.out);
-        out.nwide = (uint32_t)(out.wide.size() / 16);
+        out.nwide = (uint32_t)(out.wide.size() / 12);
     }
 
     // Triangles in leaf order, with the derived data of Triangle::update (main.cpp:527-536).

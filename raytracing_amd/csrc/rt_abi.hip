@@ -24,7 +24,7 @@ void set_error(const std::string &msg) { g_error = msg; }
 // Path records, index queues, queue counters and work cursors of the wavefront pipeline for
 // kNoAllocPaths paths in flight, laid out back to back in one array that is part of the library's code
 // object: every GPU the library runs on holds its own copy from the first launch on that GPU until the
-// process ends (155 MB).  Host code must not use the array's name as an address: the address on a
+// process ends (164 MB).  Host code must not use the array's name as an address: the address on a
 // given GPU comes from hipGetSymbolAddress with that GPU current (scratch_of below).
 namespace {
 constexpr uint32_t kNoAllocPaths = RT_NOALLOC_MAX_PIXELS;  // one path per pixel at least
@@ -34,7 +34,8 @@ constexpr size_t kScratchC = kScratchLum + (size_t)kNoAllocPaths * 16;        //
 constexpr size_t kScratchHit = kScratchC + (size_t)kNoAllocPaths * 8;         // float2[paths]
 constexpr size_t kScratchQueue0 = kScratchHit + (size_t)kNoAllocPaths * 8;    // uint32_t[paths]
 constexpr size_t kScratchQueue1 = kScratchQueue0 + (size_t)kNoAllocPaths * 4; // uint32_t[paths]
-constexpr size_t kScratchBin = kScratchQueue1 + (size_t)kNoAllocPaths * 4;    // uint16_t[paths]
+constexpr size_t kScratchRetry = kScratchQueue1 + (size_t)kNoAllocPaths * 4; // uint32_t[paths]
+constexpr size_t kScratchBin = kScratchRetry + (size_t)kNoAllocPaths * 4;     // uint16_t[paths]
 constexpr size_t kScratchQcount = kScratchBin + (size_t)kNoAllocPaths * 2;    // uint32_t[4], padded to 256 B
 constexpr size_t kScratchCursors = kScratchQcount + 256;                      // uint32_t[kWfCursorWords]
 constexpr size_t kScratchBinHist = kScratchCursors + rt::kWfCursorWords * sizeof(uint32_t);  // uint32_t[kWfBinWords]
@@ -122,6 +123,7 @@ void free_wavefront(rt_scene *s) {
     dev_free(s, w.queue[0], cap);
     dev_free(s, w.queue[1], cap);
     dev_free(s, w.bin, cap);
+    dev_free(s, w.retry, cap);
     dev_free(s, w.qcount, (size_t)4);
     dev_free(s, w.cursors, rt::kWfCursorWords);
     dev_free(s, w.binhist, rt::kWfBinWords);
@@ -129,7 +131,7 @@ void free_wavefront(rt_scene *s) {
 }
 
 // Path records in flight per wavefront pass: whole frames of samples, up to 64 of them or about 128M
-// paths (74 B each with the queues: 9.9 GB of the 288 GB), never more than the call renders.  The
+// paths (78 B each with the queues: 10.5 GB of the 288 GB), never more than the call renders.  The
 // deeper bounces of a pass keep only a few percent of its paths alive, and every launch pays a ramp
 // and a drain of about one ray's duration, so fewer, larger launches win: 16M -> 3424, 32M -> 3656,
 // 64M -> 3763, 128M -> 3827 Mrays/s on the million-triangle 1080p depth-8 workload (4M: 1588 before
@@ -162,6 +164,7 @@ int ensure_wavefront(rt_scene *s, uint32_t npix, uint32_t slots) {
     RT_HIP(dev_alloc(s, &w.queue[0], (size_t)cap));
     RT_HIP(dev_alloc(s, &w.queue[1], (size_t)cap));
     RT_HIP(dev_alloc(s, &w.bin, (size_t)cap));
+    RT_HIP(dev_alloc(s, &w.retry, (size_t)cap));
     RT_HIP(dev_alloc(s, &w.binhist, rt::kWfBinWords));
     RT_HIP(hipMemset(w.binhist, 0, rt::kWfBinWords * sizeof(uint32_t)));
     RT_HIP(dev_alloc(s, &w.qcount, (size_t)4));
@@ -170,6 +173,8 @@ int ensure_wavefront(rt_scene *s, uint32_t npix, uint32_t slots) {
     RT_HIP(hipMemset(w.cursors, 0, rt::kWfCursorWords * sizeof(uint32_t)));
     w.capacity = cap;
     w.sort = s->sort_rays;
+    w.wide = s->wide_tree;
+    w.stack_limit = s->stack_limit;
     return RT_OK;
 }
 
@@ -278,6 +283,8 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
         return rc;                         \
     }
     RT_TRY(dev_alloc(s, &s->d_nodes, f.nodes.size() / 4));
+    RT_TRY(dev_alloc(s, &s->d_wide, f.wide.size() / 4));
+    RT_TRY(hipMemcpy(s->d_wide, f.wide.data(), f.wide.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     RT_TRY(dev_alloc(s, &s->d_tris, f.tris.size() / 4));
     RT_TRY(dev_alloc(s, &s->d_lights, f.lights.size()));
     RT_TRY(dev_alloc(s, &s->d_lnodes, f.light_nodes.size() / 4));
@@ -298,6 +305,7 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
     rtd::DevScene &v = s->view;
     v.nodes = s->d_nodes;
     v.tris = s->d_tris;
+    v.wide = s->d_wide;
     v.lights = s->d_lights;
     v.lnodes = s->d_lnodes;
     v.lrecs = s->d_lrecs;
@@ -335,6 +343,13 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
         const size_t sceneBytes = (f.nodes.size() + f.tris.size()) * 4;
         s->sort_rays = sceneBytes > (size_t)(4u << 20);
         if (const char *e = std::getenv("RT_WF_SORT")) s->sort_rays = std::atoi(e) != 0;
+        // RT_WF_WIDE=0: wf_extend walks the two-child tree; RT_WF_STACK_LIMIT=n (tests): the wide walk gives up
+        // beyond n stack entries, which sends rays through the retry kernel
+        if (const char *e = std::getenv("RT_WF_WIDE")) s->wide_tree = std::atoi(e) != 0;
+        if (const char *e = std::getenv("RT_WF_STACK_LIMIT")) {
+            const int n = std::atoi(e);
+            s->stack_limit = n < 0 ? 0 : (n > rtd::kStack ? rtd::kStack : n);
+        }
     }
     v.has_background = 0u;
     for (int k = 0; k < 3; ++k) {
@@ -357,6 +372,7 @@ void rt_scene_destroy(rt_scene *s) {
     s->timer.release();
     (void)hipFree(s->d_nodes);
     (void)hipFree(s->d_tris);
+    (void)hipFree(s->d_wide);
     (void)hipFree(s->d_lights);
     (void)hipFree(s->d_lnodes);
     (void)hipFree(s->d_lrecs);
@@ -523,8 +539,11 @@ int rt_render_noalloc_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t
     wb.queue[0] = reinterpret_cast<uint32_t *>(base + kScratchQueue0);
     wb.queue[1] = reinterpret_cast<uint32_t *>(base + kScratchQueue1);
     wb.bin = reinterpret_cast<uint16_t *>(base + kScratchBin);
+    wb.retry = reinterpret_cast<uint32_t *>(base + kScratchRetry);
     wb.binhist = reinterpret_cast<uint32_t *>(base + kScratchBinHist);
     wb.sort = s->sort_rays;
+    wb.wide = s->wide_tree;
+    wb.stack_limit = s->stack_limit;
     wb.qcount = reinterpret_cast<uint32_t *>(base + kScratchQcount);
     wb.cursors = reinterpret_cast<uint32_t *>(base + kScratchCursors);
     // the array keeps the previous call's contents: counters and cursors start from zero, the records

@@ -116,6 +116,7 @@ struct DevMaterial {
 
 struct DevScene {
     const uint4 *nodes;       // 2 x uint4 per node: 16-bit grid boxes of both children + two references
+    const uint4 *wide;        // 3 x uint4 per node: the same tree with up to four children per node, 8-bit boxes (wf_extend walks it)
     const float4 *tris;       // 4 x float4 per triangle, leaf order
     const uint4 *lnodes;      // tree over the light triangles only (same node format, own grid)
     const float4 *lrecs;      // 4 x float4 per light in that tree's leaf order; q3 = (bits(light index), bits(leaf position), pdfConst, 0)
@@ -219,7 +220,7 @@ __device__ __forceinline__ bool tri_test(float4 q0, float4 q1, float4 q2, v3 o, 
 // height bound (kStack inner levels) is what keeps the stack from overflowing.
 constexpr int kSentinel = 0x7FFFFFFF;  // "stack is empty": never a node index, never a leaf reference
 
-template <bool COUNT, int EXIT_LANES = 0, bool HELP = false>
+template <bool COUNT, int EXIT_LANES = 0, bool HELP = false, bool WIDE = false>
 struct Traversal {
     struct f2 {
         float x, y;
@@ -235,6 +236,11 @@ struct Traversal {
     int sp;
     int *stack;   // this lane's column of the LDS stack
     uint32_t *xchg;  // HELP: 128 words of LDS owned by this wave
+    // WIDE: a visit pushes up to three references, so the walk is not bounded by the tree height; a push
+    // beyond `limit` entries is dropped and `overflow` set: the caller discards the walk and traces the ray
+    // again on the two-child tree
+    int limit;
+    bool overflow;
 
     // lane_stack: &lds[threadIdx.x]
     __device__ __forceinline__ void bind(int *lane_stack) { stack = lane_stack; }
@@ -272,6 +278,7 @@ struct Traversal {
         cur = (rd.x + rd.y + rd.z) == (rd.x + rd.y + rd.z) ? 0 : kSentinel;
         leaf = 0;
         sp = 0;
+        overflow = false;
     }
     __device__ __forceinline__ void idle() {  // a lane with no ray: steps are no-ops
         cur = kSentinel;
@@ -279,14 +286,35 @@ struct Traversal {
         sp = 0;
     }
     __device__ __forceinline__ bool done() const { return cur == kSentinel && leaf == 0; }
+    // Strict minimum (main.cpp:563-571).  Two triangles at exactly the same distance (a ray through a shared
+    // edge): the reference keeps whichever its own tree meets first; here the one earlier in leaf order wins,
+    // whatever tree is walked in whatever order, so that every kernel names the same triangle.
+    __device__ __forceinline__ bool closer(float t, int tri) const { return t < tBest || (t == tBest && tri < triBest); }
     __device__ __forceinline__ int pop() {
         if (sp == 0) return kSentinel;
         --sp;
         return stack[sp * kBlock];
     }
     __device__ __forceinline__ void push(int ref) {
+        if (WIDE && sp >= limit) {
+            overflow = true;
+            return;
+        }
         stack[sp * kBlock] = ref;
         ++sp;
+    }
+    // (near, far) distances of one child box given its three words, far already cut at the best hit
+    __device__ __forceinline__ f2 box_span(uint32_t wx, uint32_t wy, uint32_t wz) const {
+        const f2 ax = slab(wx, rx, ga.x, gn.x, gf.x), ay = slab(wy, ry, ga.y, gn.y, gf.y), az = slab(wz, rz, ga.z, gn.z, gf.z);
+        return f2{__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(ax.x, ay.x), az.x), 0.f),
+                  __builtin_fminf(__builtin_fminf(__builtin_fminf(ax.y, ay.y), az.y), tBest)};
+    }
+    static __device__ __forceinline__ void order(float &ka, int &ra, float &kb, int &rb) {  // nearer one first
+        if (kb < ka) {
+            const float k = ka;
+            const int r = ra;
+            ka = kb, ra = rb, kb = k, rb = r;
+        }
     }
     // One axis of one child box, word = lo | hi << 16: rotating the word by 16 bits for a negative
     // direction puts the near plane in the low half, so no min/max per axis is needed.  Returns the
@@ -301,6 +329,58 @@ struct Traversal {
     __device__ __forceinline__ void step(const DevScene &S, TraceStats &st) {
         const uint32_t nodes0 = st.nodes, tris0 = st.tris;
         while (cur >= 0 && cur != kSentinel) {
+            if (WIDE) {
+                // Four children per visit: the hit ones are entered nearest first, the others pushed so that
+                // they pop in order of distance.  A child that is missed sorts last with an infinite key.
+                // Boxes: 8 bits per plane in the node's frame (origin on the scene grid, a shift per axis):
+                // plane distance = q * (ga * 2^s) + (origin * ga + g), two roundings instead of one, both
+                // inside the margin of gn / gf (four times the single-rounding bound).
+                const uint4 *np = S.wide + 3 * (size_t)cur;
+                const uint4 n0 = np[0], n1 = np[1], n3 = np[2];
+                if (COUNT) ++st.nodes;
+                const float fox = (float)(n1.z & 0xffffu), foy = (float)(n1.z >> 16), foz = (float)(n1.w & 0xffffu);
+                const float ax = __builtin_ldexpf(ga.x, (int)((n1.w >> 16) & 15u)), ay = __builtin_ldexpf(ga.y, (int)((n1.w >> 20) & 15u)),
+                            az = __builtin_ldexpf(ga.z, (int)((n1.w >> 24) & 15u));
+                const float bnx = __builtin_fmaf(fox, ga.x, gn.x), bfx = __builtin_fmaf(fox, ga.x, gf.x);
+                const float bny = __builtin_fmaf(foy, ga.y, gn.y), bfy = __builtin_fmaf(foy, ga.y, gf.y);
+                const float bnz = __builtin_fmaf(foz, ga.z, gn.z), bfz = __builtin_fmaf(foz, ga.z, gf.z);
+                // near planes are the hi ones where the direction is negative
+                const uint32_t wnx = rx ? n0.y : n0.x, wfx = rx ? n0.x : n0.y, wny = ry ? n0.w : n0.z, wfy = ry ? n0.z : n0.w,
+                               wnz = rz ? n1.y : n1.x, wfz = rz ? n1.x : n1.y;
+                const uint32_t nch = n1.w >> 28;
+#define RT_WIDE_SPAN(k)                                                                                                      \
+    f2 {                                                                                                                     \
+        __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf((float)((wnx >> (8 * k)) & 0xffu), ax, bnx),          \
+                                                        __builtin_fmaf((float)((wny >> (8 * k)) & 0xffu), ay, bny)),         \
+                                        __builtin_fmaf((float)((wnz >> (8 * k)) & 0xffu), az, bnz)),                         \
+                        0.f),                                                                                                \
+            __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaf((float)((wfx >> (8 * k)) & 0xffu), ax, bfx),      \
+                                                            __builtin_fmaf((float)((wfy >> (8 * k)) & 0xffu), ay, bfy)),     \
+                                            __builtin_fmaf((float)((wfz >> (8 * k)) & 0xffu), az, bfz)),                     \
+                            tBest)                                                                                           \
+    }
+                const f2 s0 = RT_WIDE_SPAN(0), s1 = RT_WIDE_SPAN(1), s2 = RT_WIDE_SPAN(2), s3 = RT_WIDE_SPAN(3);
+#undef RT_WIDE_SPAN
+                const float none = 3.0e38f;
+                float k0 = s0.x <= s0.y ? s0.x : none, k1 = s1.x <= s1.y ? s1.x : none,
+                      k2 = (nch > 2u && s2.x <= s2.y) ? s2.x : none, k3 = (nch > 3u && s3.x <= s3.y) ? s3.x : none;
+                int r0 = (int)n3.x, r1 = (int)n3.y, r2 = (int)n3.z, r3 = (int)n3.w;
+                order(k0, r0, k1, r1);
+                order(k2, r2, k3, r3);
+                order(k0, r0, k2, r2);
+                order(k1, r1, k3, r3);
+                order(k1, r1, k2, r2);
+                if (k3 < none) push(r3);
+                if (k2 < none) push(r2);
+                if (k1 < none) push(r1);
+                cur = k0 < none ? r0 : pop();
+                if (cur < 0 && leaf == 0) {
+                    leaf = cur;
+                    cur = pop();
+                }
+                if (__builtin_popcountll(__ballot(leaf == 0)) <= EXIT_LANES) break;
+                continue;
+            }
             const uint4 *np = S.nodes + 2 * (size_t)cur;
             const uint4 n0 = np[0], n1 = np[1];
             if (COUNT) ++st.nodes;
@@ -352,7 +432,7 @@ struct Traversal {
                     const float4 *tp = S.tris + 4 * (size_t)(first + k);
                     float t;
                     if (COUNT) ++st.tris;
-                    if (tri_test(tp[0], tp[1], tp[2], o, d, t) && t < tBest) {
+                    if (tri_test(tp[0], tp[1], tp[2], o, d, t) && closer(t, (int)(first + k))) {
                         tBest = t;
                         triBest = (int)(first + k);
                     }
@@ -399,20 +479,20 @@ struct Traversal {
             }
             if (has) {
                 if (COUNT) st.tris += cnt;
-                if (hit && t < tBest) {
+                if (hit && closer(t, (int)first)) {
                     tBest = t;
                     triBest = (int)first;
                 }
                 if (lend) {
-                    const float t2 = __uint_as_float(xchg[64 + drank]);
-                    if (t2 < tBest) {
+                    const float t2 = __uint_as_float(xchg[64 + drank]);  // kInf when the helper's test missed
+                    if (t2 < kInf && closer(t2, (int)first + 1)) {
                         tBest = t2;
                         triBest = (int)first + 1;
                     }
                 } else if (cnt == 2u) {  // more two-triangle leaves than idle lanes: test it here
                     const float4 *tp = S.tris + 4 * (size_t)(first + 1u);
                     float t2;
-                    if (tri_test(tp[0], tp[1], tp[2], o, d, t2) && t2 < tBest) {
+                    if (tri_test(tp[0], tp[1], tp[2], o, d, t2) && closer(t2, (int)first + 1)) {
                         tBest = t2;
                         triBest = (int)first + 1;
                     }

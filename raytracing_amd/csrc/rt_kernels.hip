@@ -256,6 +256,7 @@ __global__ __launch_bounds__(kBlock) void wf_generate(DevScene S, rt::RenderPara
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         qcount[0] = npaths;
         qcount[1] = 0u;
+        qcount[2] = 0u;  // wf_extend's retry list
     }
     if (blockIdx.x == 0 && threadIdx.x < kShards) cursors[threadIdx.x * kCursorStride] = 0u;  // first extend pass
 }
@@ -277,13 +278,18 @@ constexpr int kRefill = 20;  // 4: -3 %, 12: -1 %, 16 to 24: within 0.5 %, 32: -
 
 // PRIMS: the scene holds analytic primitives, folded into every finished walk.  A separate instantiation:
 // with the fold compiled into the one kernel, scenes without primitives traced 12 % slower.
-template <bool COUNT, bool PRIMS>
+// WIDE: walks the four-child tree; a ray whose walk ran out of stack (Traversal::overflow) gets no hit here,
+// its slot goes to the `retry` list and wf_extend_retry traces it on the two-child tree.
+template <bool COUNT, bool PRIMS, bool WIDE>
 __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const uint32_t *__restrict__ queue,
                                                      const uint32_t *__restrict__ qcount_in,
-                                                     uint32_t *__restrict__ qcount_zero, uint32_t *__restrict__ cursors) {
+                                                     uint32_t *__restrict__ qcount_zero, uint32_t *__restrict__ cursors,
+                                                     uint32_t *__restrict__ retry, uint32_t *__restrict__ retry_count,
+                                                     int stack_limit) {
     __shared__ int s_stack[kStack * kBlock];
     __shared__ uint32_t s_xchg[4][128];
-    Traversal<COUNT, kExitLanes, true> T;
+    Traversal<COUNT, kExitLanes, true, WIDE> T;
+    T.limit = stack_limit;
     T.xchg = s_xchg[threadIdx.x >> 6];
     const uint32_t count = *qcount_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) *qcount_zero = 0u;  // the queue the next shade pass fills
@@ -298,10 +304,14 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
     TraceStats st{0, 0, 0, 0};
     for (;;) {
         if (hasRay && T.done()) {
-            if (PRIMS) analytic_closest(S, T.o, T.d, T.tBest, T.triBest);
-            V.hit[slot] = make_float2(T.tBest, __int_as_float(T.triBest));
+            if (WIDE && T.overflow) {
+                retry[atomicAdd(retry_count, 1u)] = slot;
+            } else {
+                if (PRIMS) analytic_closest(S, T.o, T.d, T.tBest, T.triBest);
+                V.hit[slot] = make_float2(T.tBest, __int_as_float(T.triBest));
+                ++segs;
+            }
             hasRay = false;
-            ++segs;
         }
         const unsigned long long idleMask = __ballot(!hasRay);
         const int nIdle = __builtin_popcountll(idleMask);
@@ -347,6 +357,26 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
     if (segs) add_counters(S, segs, st, 0u, COUNT);
 }
 
+// The rays wf_extend<WIDE> gave up on, one lane each, on the two-child tree (whose height bounds the stack).
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void wf_extend_retry(DevScene S, WfView V, const uint32_t *__restrict__ retry,
+                                                           const uint32_t *__restrict__ retry_count) {
+    __shared__ int s_stack[kStack * kBlock];
+    const uint32_t count = *retry_count;
+    uint32_t segs = 0;
+    TraceStats st{0, 0, 0, 0};
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < count; k += gridDim.x * kBlock) {
+        const uint32_t slot = retry[k];
+        const float4 r0 = V.ray[2 * (size_t)slot], r1 = V.ray[2 * (size_t)slot + 1];
+        float t;
+        int tri;
+        closest_hit<COUNT>(S, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), s_stack + threadIdx.x, t, tri, st);
+        V.hit[slot] = make_float2(t, __int_as_float(tri));
+        ++segs;
+    }
+    if (segs) add_counters(S, segs, st, 0u, COUNT);
+}
+
 // Shades the hits of the input queue and appends the surviving paths to the output queue.
 // Appending is hierarchical, because one word of global memory takes only about 88 atomic adds per
 // microsecond however many CUs issue them: with one global atomic per wave and round this kernel
@@ -363,7 +393,8 @@ template <bool TREE>
 __global__ __launch_bounds__(kBlock, TREE ? 1 : 6) void wf_shade(DevScene S, WfView V, const uint32_t *__restrict__ queue,
                                                     const uint32_t *__restrict__ qcount_in,
                                                     uint32_t *__restrict__ queue_out, uint32_t *__restrict__ qcount_out,
-                                                    uint32_t *__restrict__ cursors, uint32_t depth, uint32_t want_bins) {
+                                                    uint32_t *__restrict__ cursors, uint32_t depth, uint32_t want_bins,
+                                                    uint32_t *__restrict__ retry_count) {
     __shared__ uint32_t s_buf[kAppendBuf];  // path slot | ray-sorting cell << 27 would not fit: cells ride in s_bin
     __shared__ uint16_t s_bin[kAppendBuf];
     __shared__ uint32_t s_count, s_base;
@@ -372,6 +403,7 @@ __global__ __launch_bounds__(kBlock, TREE ? 1 : 6) void wf_shade(DevScene S, WfV
     const LightCache LC = load_light_cache(S, s_lights, s_stack + (TREE ? threadIdx.x : 0));
     const uint32_t count = *qcount_in;
     if (blockIdx.x == 0 && threadIdx.x < kShards) cursors[threadIdx.x * kCursorStride] = 0u;  // next extend pass
+    if (blockIdx.x == 0 && threadIdx.x == 0) *retry_count = 0u;
     if (threadIdx.x == 0) s_count = 0u;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
@@ -578,6 +610,7 @@ inline uint32_t pixel_grid(uint32_t W, uint32_t H) { return ((W + 15u) / 16u) * 
 inline uint32_t ceil_blocks(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 constexpr uint32_t kPersistentBlocks = 256u * 8u;  // 256 CUs x 8 workgroups for grid-stride kernels
 constexpr uint32_t kExtendBlocks = 256u * 6u;      // 256 CUs x 6 resident workgroups (24 KB of LDS each)
+constexpr uint32_t kRetryGrid = 64;                // the retry list is empty or nearly so
 
 }  // namespace
 
@@ -666,14 +699,21 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
             const int fill = (qu == 0) ? 1 : 0;
             const bool sort = wb.sort && b >= kSortFromBounce && b + 1 < bounces;
             timer.begin(kKernExtend, stream);
-            auto ext = S.nprims ? (count ? wf_extend<true, true> : wf_extend<false, true>)
-                                : (count ? wf_extend<true, false> : wf_extend<false, false>);
-            hipLaunchKernelGGL(ext, dim3(egrid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in, wb.qcount + out, wb.cursors);
+            uint32_t *retry = wb.retry, *retryCount = wb.qcount + 2;
+            auto ext = wb.wide ? (S.nprims ? (count ? wf_extend<true, true, true> : wf_extend<false, true, true>)
+                                           : (count ? wf_extend<true, false, true> : wf_extend<false, false, true>))
+                               : (S.nprims ? (count ? wf_extend<true, true, false> : wf_extend<false, true, false>)
+                                           : (count ? wf_extend<true, false, false> : wf_extend<false, false, false>));
+            hipLaunchKernelGGL(ext, dim3(egrid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in, wb.qcount + out, wb.cursors,
+                               retry, retryCount, wb.stack_limit);
+            if (wb.wide)
+                hipLaunchKernelGGL(count ? wf_extend_retry<true> : wf_extend_retry<false>, dim3(kRetryGrid), dim3(kBlock), 0, stream, S,
+                                   V, retry, retryCount);
             timer.end(stream);
             timer.begin(kKernShade, stream);
             hipLaunchKernelGGL(S.light_tree ? wf_shade<true> : wf_shade<false>, dim3(grid), dim3(kBlock), 0, stream, S, V,
                                qshade, wb.qcount + in, wb.queue[fill], wb.qcount + out, wb.cursors,
-                               rp.max_depth - (rp.max_depth ? b : 0u), sort ? 1u : 0u);
+                               rp.max_depth - (rp.max_depth ? b : 0u), sort ? 1u : 0u, wb.qcount + 2);
             timer.end(stream);
             qu = qs = fill;
             if (sort) {

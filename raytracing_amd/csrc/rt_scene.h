@@ -11,6 +11,7 @@ struct rt_scene {
     std::shared_ptr<const rt::FlatScene> flat;  // host copy of the flattened structure (shared by the scenes of an rt_multi)
     rtd::DevScene view{};
     uint4 *d_nodes = nullptr;
+    uint4 *d_wide = nullptr;
     float4 *d_tris = nullptr;
     uint32_t *d_lights = nullptr;
     uint4 *d_lnodes = nullptr;
@@ -23,6 +24,8 @@ struct rt_scene {
     uint64_t replay_words = 0;
     uint64_t device_bytes = 0;
     bool counting = false;
+    bool wide_tree = true;   // wavefront pipeline: wf_extend walks the four-child tree
+    int stack_limit = rtd::kStack;
     bool sort_rays = false;  // wavefront pipeline: regroup the rays of the later bounces by cell
     uint32_t nmat = 0;
     rt::KernelTimer timer;

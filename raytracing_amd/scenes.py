@@ -233,9 +233,12 @@ def cornell_box(path):
     root = g.node(children=[1, 2, 3, 4])            # node 0: parent of everything below
     g.node(mesh=walls)                               # 1
     g.node(mesh=lamp)                                # 2
-    g.node(mesh=cube_m, translation=(-0.38, -0.4, -0.35), rotation=_quat_axis_angle((0, 1, 0), 0.32),
+    # The boxes float 2 mm above the floor: a box face lying IN the floor plane gives every ray that leaves the
+    # glass box downwards two hits at exactly the same distance, and which one wins depends on the order a tree
+    # is walked in (the reference's strict minimum, main.cpp:563-571, keeps the first it meets).
+    g.node(mesh=cube_m, translation=(-0.38, -0.398, -0.35), rotation=_quat_axis_angle((0, 1, 0), 0.32),
            scale=(0.58, 1.2, 0.58))                  # 3: tall mirror box
-    g.node(mesh=cube_g, translation=(0.4, -0.7, 0.3), rotation=_quat_axis_angle((0, 1, 0), -0.3),
+    g.node(mesh=cube_g, translation=(0.4, -0.698, 0.3), rotation=_quat_axis_angle((0, 1, 0), -0.3),
            scale=(0.56, 0.6, 0.56))                  # 4: glass box
     cam = g.camera(0.6911)
     g.node(camera=cam, translation=(0.0, 0.0, 3.4))  # 5
