@@ -385,7 +385,10 @@ __global__ __launch_bounds__(kBlock) void wf_extend_retry(DevScene S, WfView V, 
 // workgroup (one LDS atomic per wave and round, lanes write at their ballot-prefix offset); when the
 // buffer is nearly full, and after the last round, the workgroup reserves space in the global
 // queue with ONE atomic and copies the buffer out with coalesced stores.
-constexpr uint32_t kAppendBuf = 2048;  // LDS entries per workgroup (8 KB); flushed above kAppendBuf - kBlock
+constexpr uint32_t kAppendBuf = 2048;  // LDS entries per workgroup (8 KB + 4 KB of cells); flushed above kAppendBuf - kBlock
+// The light-tree variant keeps a 24 KB traversal stack in LDS as well: with half the buffer four of its
+// workgroups still fit a CU (with the full one only three did: 89.8 -> 109 ms on the 15 360-light frame).
+constexpr uint32_t kAppendBufTree = 1024;
 
 // Six waves per SIMD (at most 80 VGPRs): left alone the compiler takes 83 and a wave less; no spills (-2 %).
 // (Not the light-tree variant: its stack in LDS bounds it to fewer waves anyway.)
@@ -395,8 +398,9 @@ __global__ __launch_bounds__(kBlock, TREE ? 1 : 6) void wf_shade(DevScene S, WfV
                                                     uint32_t *__restrict__ queue_out, uint32_t *__restrict__ qcount_out,
                                                     uint32_t *__restrict__ cursors, uint32_t depth, uint32_t want_bins,
                                                     uint32_t *__restrict__ retry_count) {
-    __shared__ uint32_t s_buf[kAppendBuf];  // path slot | ray-sorting cell << 27 would not fit: cells ride in s_bin
-    __shared__ uint16_t s_bin[kAppendBuf];
+    constexpr uint32_t kBuf = TREE ? kAppendBufTree : kAppendBuf;
+    __shared__ uint32_t s_buf[kBuf];
+    __shared__ uint16_t s_bin[kBuf];
     __shared__ uint32_t s_count, s_base;
     __shared__ LightCacheStorage s_lights;
     __shared__ int s_stack[TREE ? kStack * kBlock : 1];  // light_pdf's walk of the light tree
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(kBlock, TREE ? 1 : 6) void wf_shade(DevScene S, WfV
         }
         __syncthreads();
         const uint32_t n = s_count;
-        if (n > kAppendBuf - kBlock || (r + 1 == rounds && n)) {  // uniform: every thread read the same s_count
+        if (n > kBuf - kBlock || (r + 1 == rounds && n)) {  // uniform: every thread read the same s_count
             if (threadIdx.x == 0) s_base = atomicAdd(qcount_out, n);
             __syncthreads();
             const uint32_t gbase = s_base;
