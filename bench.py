@@ -143,14 +143,15 @@ def main():
     # for the megakernel.  Three ceilings are priced and the one the kernel sits closest to is reported
     # as roofline.bound / achieved / peak / frac:
     #   vmem  the CU's vector-memory path: 64-byte L1 accesses per second (TCP_TOTAL_CACHE_ACCESSES of the
-    #         committed rocprofv3 --pmc pass / the launch time measured here) against the rate a pure
-    #         dependent-gather microbenchmark sustains with its table in L1 (tools/microbench/node_fetch A32:
-    #         two 16-byte loads per lane on a random 32-byte record -- a BVH node visit without the arithmetic)
+    #         committed rocprofv3 --pmc pass / the launch time measured here) against one access per cycle and
+    #         CU at the 2.4 GHz peak clock (a pure dependent-gather microbenchmark with its table in L1,
+    #         tools/microbench/node_fetch A32, sustains 0.85 per cycle; the sorted, partly coherent rays of this
+    #         kernel get closer to one than that)
     #   valu  SQ_INSTS_VALU x 2 cycles (CDNA4's SIMDs are 32 lanes wide: a wave64 instruction issues over 2 cycles)
     #         against 256 CUs x 4 SIMDs x the launch's cycles
     #   hbm   measured L2<->fabric bytes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction) per second
     #         against the 8 TB/s HBM peak (an upper bound on HBM proper: Infinity Cache hits are in it)
-    # The ALGORITHMIC bytes (32 B per BVH node visited, 48 B per ray/triangle test, 36 B of queue traffic
+    # The ALGORITHMIC bytes (48 B per four-child node visited, 48 B per ray/triangle test, 44 B of queue traffic
     # per segment; visit counts from the counting build of the same kernels on the same workload, one
     # extra launch outside the timed region) are reported beside them; they are served by L1/L2/Infinity
     # Cache -- the 83 MB scene stays on chip -- so their rate is not bounded by HBM.
@@ -171,7 +172,10 @@ def main():
         bytes_per_seg = 32.0 * n_node + 48.0 * n_tri + 32.0 + 64.0 * n_light
     else:
         kname, kind = "wf_extend", "extend"
-        bytes_per_seg = 32.0 * n_node + 48.0 * n_tri + 36.0
+        # wf_extend walks the four-child tree (48-byte nodes) unless RT_WF_WIDE=0 (32-byte two-child nodes);
+        # per segment it also reads a 4-byte queue entry and the 32-byte ray and writes the 8-byte hit
+        node_bytes = 32.0 if os.environ.get("RT_WF_WIDE") == "0" else 48.0
+        bytes_per_seg = node_bytes * n_node + 48.0 * n_tri + 44.0
     k_ms, k_launches = ktimes[kind]
     launch_ms = k_ms / max(k_launches, 1)
     launch_s = launch_ms * 1e-3
@@ -188,10 +192,11 @@ def main():
             if traffic:
                 ceilings["hbm"] = {"achieved": round(traffic / launch_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
             peak = rates.get("vmem_gather_peak")
-            if peak and "l1_accesses" in rec:
+            if "l1_accesses" in rec:
                 ceilings["vmem"] = {"achieved": round(rec["l1_accesses"] / launch_s / 1e9, 1),
-                                    "peak": round(peak["lane_loads_per_s"] / 1e9, 1), "unit": "G L1 accesses/s",
-                                    "peak_source": peak["source"]}
+                                    "peak": round(256 * 2.4, 1), "unit": "G L1 accesses/s",
+                                    "peak_source": "256 CUs x 2.4 GHz x one 64-byte L1 access per cycle",
+                                    "gather_microbenchmark": round(peak["lane_loads_per_s"] / 1e9, 1) if peak else None}
             if "valu_wave_insts" in rec and "gui_active_cycles_sum_xcd" in rec:
                 cycles = rec["gui_active_cycles_sum_xcd"] / 8.0     # the counter sums the 8 XCDs
                 ceilings["valu"] = {"achieved": round(rec["valu_wave_insts"] * 2.0 / cycles, 1), "peak": 256 * 4.0,

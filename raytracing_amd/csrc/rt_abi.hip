@@ -24,7 +24,7 @@ void set_error(const std::string &msg) { g_error = msg; }
 // Path records, index queues, queue counters and work cursors of the wavefront pipeline for
 // kNoAllocPaths paths in flight, laid out back to back in one array that is part of the library's code
 // object: every GPU the library runs on holds its own copy from the first launch on that GPU until the
-// process ends (164 MB).  Host code must not use the array's name as an address: the address on a
+// process ends (172 MB).  Host code must not use the array's name as an address: the address on a
 // given GPU comes from hipGetSymbolAddress with that GPU current (scratch_of below).
 namespace {
 constexpr uint32_t kNoAllocPaths = RT_NOALLOC_MAX_PIXELS;  // one path per pixel at least
@@ -34,8 +34,8 @@ constexpr size_t kScratchC = kScratchLum + (size_t)kNoAllocPaths * 16;        //
 constexpr size_t kScratchHit = kScratchC + (size_t)kNoAllocPaths * 8;         // float2[paths]
 constexpr size_t kScratchQueue0 = kScratchHit + (size_t)kNoAllocPaths * 8;    // uint32_t[paths]
 constexpr size_t kScratchQueue1 = kScratchQueue0 + (size_t)kNoAllocPaths * 4; // uint32_t[paths]
-constexpr size_t kScratchRetry = kScratchQueue1 + (size_t)kNoAllocPaths * 4; // uint32_t[paths]
-constexpr size_t kScratchBin = kScratchRetry + (size_t)kNoAllocPaths * 4;     // uint16_t[paths]
+constexpr size_t kScratchRetry = kScratchQueue1 + (size_t)kNoAllocPaths * 4; // uint32_t[2 * paths]
+constexpr size_t kScratchBin = kScratchRetry + (size_t)kNoAllocPaths * 8;     // uint16_t[paths]
 constexpr size_t kScratchQcount = kScratchBin + (size_t)kNoAllocPaths * 2;    // uint32_t[4], padded to 256 B
 constexpr size_t kScratchCursors = kScratchQcount + 256;                      // uint32_t[kWfCursorWords]
 constexpr size_t kScratchBinHist = kScratchCursors + rt::kWfCursorWords * sizeof(uint32_t);  // uint32_t[kWfBinWords]
@@ -123,7 +123,7 @@ void free_wavefront(rt_scene *s) {
     dev_free(s, w.queue[0], cap);
     dev_free(s, w.queue[1], cap);
     dev_free(s, w.bin, cap);
-    dev_free(s, w.retry, cap);
+    dev_free(s, w.retry, cap * 2);
     dev_free(s, w.qcount, (size_t)4);
     dev_free(s, w.cursors, rt::kWfCursorWords);
     dev_free(s, w.binhist, rt::kWfBinWords);
@@ -131,7 +131,7 @@ void free_wavefront(rt_scene *s) {
 }
 
 // Path records in flight per wavefront pass: whole frames of samples, up to 64 of them or about 128M
-// paths (78 B each with the queues: 10.5 GB of the 288 GB), never more than the call renders.  The
+// paths (82 B each with the queues: 11 GB of the 288 GB), never more than the call renders.  The
 // deeper bounces of a pass keep only a few percent of its paths alive, and every launch pays a ramp
 // and a drain of about one ray's duration, so fewer, larger launches win: 16M -> 3424, 32M -> 3656,
 // 64M -> 3763, 128M -> 3827 Mrays/s on the million-triangle 1080p depth-8 workload (4M: 1588 before
@@ -164,7 +164,7 @@ int ensure_wavefront(rt_scene *s, uint32_t npix, uint32_t slots) {
     RT_HIP(dev_alloc(s, &w.queue[0], (size_t)cap));
     RT_HIP(dev_alloc(s, &w.queue[1], (size_t)cap));
     RT_HIP(dev_alloc(s, &w.bin, (size_t)cap));
-    RT_HIP(dev_alloc(s, &w.retry, (size_t)cap));
+    RT_HIP(dev_alloc(s, &w.retry, (size_t)cap * 2));
     RT_HIP(dev_alloc(s, &w.binhist, rt::kWfBinWords));
     RT_HIP(hipMemset(w.binhist, 0, rt::kWfBinWords * sizeof(uint32_t)));
     RT_HIP(dev_alloc(s, &w.qcount, (size_t)4));

@@ -225,7 +225,8 @@ struct WfView {
     float4 *ray;    // [2i] = (o.xyz, d.x)  [2i+1] = (d.y, d.z, throughput.x, throughput.y)
     float2 *c;      // [i] = (throughput.z, bits(rng))
     float4 *lum;    // [i] = (radiance gathered so far .xyz, 0)
-    float2 *hit;    // [i] = (hit t, bits(hit triangle)) of path i's current ray
+    float2 *hit;    // (hit t, bits(hit triangle)) of a path's current ray: at its queue position, or at its slot when
+                    // the queue wf_extend traces is a regrouped copy of the one wf_shade walks (hit_by_slot)
     uint16_t *bin;  // [j] = ray-sorting cell of the ray at position j of the queue wf_shade is filling
     uint32_t cap;
 };
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
                                                      const uint32_t *__restrict__ qcount_in,
                                                      uint32_t *__restrict__ qcount_zero, uint32_t *__restrict__ cursors,
                                                      uint32_t *__restrict__ retry, uint32_t *__restrict__ retry_count,
-                                                     int stack_limit) {
+                                                     int stack_limit, uint32_t hit_by_slot) {
     __shared__ int s_stack[kStack * kBlock];
     __shared__ uint32_t s_xchg[4][128];
     Traversal<COUNT, kExitLanes, true, WIDE> T;
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
     const uint32_t lane = threadIdx.x & 63u;
     T.idle();
     T.bind(s_stack + threadIdx.x);
-    uint32_t slot = 0, segs = 0;  // path slot of this lane's ray: where its hit goes
+    uint32_t slot = 0, hitAt = 0, segs = 0;  // path slot of this lane's ray, and where its hit goes
     bool hasRay = false;
     uint32_t chunkNext = 0, chunkEnd = 0;  // wave-uniform
     uint32_t shard = blockIdx.x % kShards, dry = 0;  // wave-uniform: current shard, shards found empty in a row
@@ -305,10 +306,12 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
     for (;;) {
         if (hasRay && T.done()) {
             if (WIDE && T.overflow) {
-                retry[atomicAdd(retry_count, 1u)] = slot;
+                const uint32_t at = atomicAdd(retry_count, 1u);  // (slot, where its hit goes)
+                retry[2 * (size_t)at] = slot;
+                retry[2 * (size_t)at + 1] = hitAt;
             } else {
                 if (PRIMS) analytic_closest(S, T.o, T.d, T.tBest, T.triBest);
-                V.hit[slot] = make_float2(T.tBest, __int_as_float(T.triBest));
+                V.hit[hitAt] = make_float2(T.tBest, __int_as_float(T.triBest));
                 ++segs;
             }
             hasRay = false;
@@ -344,6 +347,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
                 if (!hasRay && rank >= given && rank < given + take) {
                     const uint32_t qpos = chunkNext + (rank - given);
                     slot = queue ? queue[qpos] : qpos;
+                    hitAt = hit_by_slot ? slot : qpos;  // dense 8-byte stores when wf_shade walks this same queue
                     const float4 r0 = V.ray[2 * (size_t)slot], r1 = V.ray[2 * (size_t)slot + 1];
                     T.start(S, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y));
                     hasRay = true;
@@ -366,12 +370,12 @@ __global__ __launch_bounds__(kBlock) void wf_extend_retry(DevScene S, WfView V, 
     uint32_t segs = 0;
     TraceStats st{0, 0, 0, 0};
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < count; k += gridDim.x * kBlock) {
-        const uint32_t slot = retry[k];
+        const uint32_t slot = retry[2 * (size_t)k], hitAt = retry[2 * (size_t)k + 1];
         const float4 r0 = V.ray[2 * (size_t)slot], r1 = V.ray[2 * (size_t)slot + 1];
         float t;
         int tri;
         closest_hit<COUNT>(S, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), s_stack + threadIdx.x, t, tri, st);
-        V.hit[slot] = make_float2(t, __int_as_float(tri));
+        V.hit[hitAt] = make_float2(t, __int_as_float(tri));
         ++segs;
     }
     if (segs) add_counters(S, segs, st, 0u, COUNT);
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(kBlock, TREE ? 1 : 6) void wf_shade(DevScene S, WfV
                                                     const uint32_t *__restrict__ qcount_in,
                                                     uint32_t *__restrict__ queue_out, uint32_t *__restrict__ qcount_out,
                                                     uint32_t *__restrict__ cursors, uint32_t depth, uint32_t want_bins,
-                                                    uint32_t *__restrict__ retry_count) {
+                                                    uint32_t *__restrict__ retry_count, uint32_t hit_by_slot) {
     constexpr uint32_t kBuf = TREE ? kAppendBufTree : kAppendBuf;
     __shared__ uint32_t s_buf[kBuf];
     __shared__ uint16_t s_bin[kBuf];
@@ -416,9 +420,10 @@ __global__ __launch_bounds__(kBlock, TREE ? 1 : 6) void wf_shade(DevScene S, WfV
     const uint32_t stride = gridDim.x * kBlock;
     const uint32_t rounds = (count + stride - 1u) / stride;
     // The queue entry of a round is fetched one round ahead; the round then waits for one trip to memory:
-    // the path's record and its hit side by side (both live at the path's slot).  `queue` is the order in
-    // which the previous shading pass appended the survivors -- ascending slots within each run -- not
-    // the cell order wf_extend traced them in, so the records stream instead of being gathered.
+    // the path's record and its hit side by side.  `queue` is the order in which the previous shading pass
+    // appended the survivors -- ascending slots within each run -- so the records stream instead of being
+    // gathered.  When wf_extend traced a copy of that queue regrouped by cell, it left the hits at the paths'
+    // slots (hit_by_slot); otherwise they lie at the queue positions, written and read densely.
     uint32_t j = blockIdx.x * kBlock + threadIdx.x;
     uint32_t iNext = 0;
     if (j < count) iNext = queue ? queue[j] : j;
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(kBlock, TREE ? 1 : 6) void wf_shade(DevScene S, WfV
         const uint32_t i = iNext;
         uint32_t cell = 0;
         if (j < count) {
-            const float2 h = V.hit[i];
+            const float2 h = V.hit[hit_by_slot ? i : j];
             const float4 r0 = V.ray[2 * (size_t)i], r1 = V.ray[2 * (size_t)i + 1];
             const float2 r2 = V.c[i];
             const uint32_t jn = j + stride;
@@ -709,7 +714,7 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
                                : (S.nprims ? (count ? wf_extend<true, true, false> : wf_extend<false, true, false>)
                                            : (count ? wf_extend<true, false, false> : wf_extend<false, false, false>));
             hipLaunchKernelGGL(ext, dim3(egrid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in, wb.qcount + out, wb.cursors,
-                               retry, retryCount, wb.stack_limit);
+                               retry, retryCount, wb.stack_limit, (qs != qu) ? 1u : 0u);
             if (wb.wide)
                 hipLaunchKernelGGL(count ? wf_extend_retry<true> : wf_extend_retry<false>, dim3(kRetryGrid), dim3(kBlock), 0, stream, S,
                                    V, retry, retryCount);
@@ -717,7 +722,7 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
             timer.begin(kKernShade, stream);
             hipLaunchKernelGGL(S.light_tree ? wf_shade<true> : wf_shade<false>, dim3(grid), dim3(kBlock), 0, stream, S, V,
                                qshade, wb.qcount + in, wb.queue[fill], wb.qcount + out, wb.cursors,
-                               rp.max_depth - (rp.max_depth ? b : 0u), sort ? 1u : 0u, wb.qcount + 2);
+                               rp.max_depth - (rp.max_depth ? b : 0u), sort ? 1u : 0u, wb.qcount + 2, (qs != qu) ? 1u : 0u);
             timer.end(stream);
             qu = qs = fill;
             if (sort) {

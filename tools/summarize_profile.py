@@ -21,8 +21,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def short(name):
     if "<true" in name:   # counting instantiations (bench.py's one statistics launch): not the timed kernels
         return None
-    for k in ("wf_extend", "wf_shade", "wf_generate", "wf_accumulate", "k_render_mega", "k_primary", "k_intersect",
-              "k_tonemap"):
+    for k in ("wf_extend_retry", "wf_extend", "wf_shade", "wf_generate", "wf_accumulate", "wf_bin_hist", "wf_bin_scan",
+              "wf_bin_scatter", "k_render_mega", "k_primary", "k_intersect", "k_tonemap"):
         if k in name:
             return k
     return None
