@@ -687,6 +687,7 @@ constexpr uint32_t kLdsMats = 64;
 struct LightCache {
     const float4 *recs;  // LDS: 4 x float4 per cached light, light-list order
     const int *ids;      // LDS: leaf-order triangle position of each cached light
+    const float4 *sph;   // LDS: a sphere around each cached light (centre, radius), generously padded
     const float4 *mats;  // LDS: 2 x float4 per cached material
     uint32_t n;          // lights cached: min(S.nlights, kLdsLights)
     uint32_t nm;         // materials cached: min(S.nmats, kLdsMats)
@@ -695,6 +696,7 @@ struct LightCache {
 struct LightCacheStorage {
     float4 recs[4 * kLdsLights];
     float4 mats[2 * kLdsMats];
+    float4 sph[kLdsLights];
     int ids[kLdsLights];
 };
 
@@ -704,9 +706,21 @@ __device__ __forceinline__ LightCache load_light_cache(const DevScene &S, LightC
     const uint32_t nm = S.nmats < kLdsMats ? S.nmats : kLdsMats;
     for (uint32_t e = threadIdx.x; e < 4u * n; e += kBlock) st.recs[e] = S.tris[4 * (size_t)S.lights[e >> 2] + (e & 3u)];
     for (uint32_t e = threadIdx.x; e < 2u * nm; e += kBlock) st.mats[e] = reinterpret_cast<const float4 *>(S.mats)[e];
-    for (uint32_t k = threadIdx.x; k < n; k += kBlock) st.ids[k] = (int)S.lights[k];
+    for (uint32_t k = threadIdx.x; k < n; k += kBlock) {
+        const uint32_t lt = S.lights[k];
+        st.ids[k] = (int)lt;
+        // sphere through the farthest vertex around the centroid, 1 % + 1e-4 larger: whatever point the exact
+        // test can accept (it rounds at the 1e-6 level of the triangle's size and of the hit distance) is inside
+        const float4 q0 = S.tris[4 * (size_t)lt], q1 = S.tris[4 * (size_t)lt + 1], q2 = S.tris[4 * (size_t)lt + 2];
+        const v3 A = mk(q0.x, q0.y, q0.z), AB = mk(q0.w, q1.x, q1.y), AC = mk(q1.z, q1.w, q2.x);
+        const v3 g = (AB + AC) * (1.f / 3.f);  // centroid - A
+        const v3 gb = g - AB, gc = g - AC;
+        const float r2 = __builtin_fmaxf(dot(g, g), __builtin_fmaxf(dot(gb, gb), dot(gc, gc)));
+        const v3 c = A + g;
+        st.sph[k] = make_float4(c.x, c.y, c.z, __builtin_sqrtf(r2) * 1.01f + 1.0e-4f);
+    }
     __syncthreads();
-    return LightCache{st.recs, st.ids, st.mats, n, nm, lane_stack};
+    return LightCache{st.recs, st.ids, st.sph, st.mats, n, nm, lane_stack};
 }
 
 __device__ __forceinline__ DevMaterial material(const DevScene &S, const LightCache &LC, uint32_t m) {
@@ -813,9 +827,27 @@ __device__ __forceinline__ float light_pdf(const DevScene &S, const LightCache &
         if (ps < kEps || __builtin_isnan(ps) || __builtin_isinf(ps)) return 0.f;
         return ps / (float)S.nlights;
     }
+    // A ray that hits a light triangle crosses the sphere around it, and a light that is missed adds no term,
+    // so only the lights whose sphere the ray crosses get the exact test -- each lane its own candidates, in
+    // light-list order like the reference's loop: the sum is the same float.  Nearly every direction misses
+    // nearly every light; all 64 lanes stepping through the exact test of every light was half of the
+    // shading kernel's arithmetic.  `tests` counts what the reference tests: every light but the surface's own.
+    unsigned long long cand = 0ull;
     for (uint32_t k = 0; k < LC.n; ++k) {
-        if (LC.ids[k] == self) continue;
-        ++tests;
+        const float4 sp = LC.sph[k];
+        const v3 v = mk(sp.x - x.x, sp.y - x.y, sp.z - x.z);
+        const float vv = dot(v, v), b = dot(v, w), d2 = vv - b * b;
+        const bool other = LC.ids[k] != self;
+        tests += other ? 1u : 0u;
+        // vv - b^2 cancels: its rounding error grows with vv (a point 10^4 away on an analytic plane), so
+        // the radius gives way by 4e-6 vv (ten times the bound).  Written so that a NaN keeps the light: the
+        // exact test decides.
+        const float slack = 4.0e-6f * vv;
+        if (other && !(d2 > sp.w * sp.w + slack) && !(b < -(sp.w + slack))) cand |= 1ull << k;
+    }
+    while (cand) {
+        const uint32_t k = (uint32_t)__builtin_ctzll(cand);
+        cand &= cand - 1ull;
         const float4 *tp = LC.recs + 4 * k;
         float t;
         if (tri_test(tp[0], tp[1], tp[2], x, w, t)) ps += light_term(tp[2], tp[3], x, w, t);
