@@ -226,6 +226,14 @@ int rt_flat_get(const rt_flat *f, uint32_t info[4], float grid[6], uint32_t *nod
  * record (16 floats) per light in this tree's leaf order, word 12 = index in the light list,
  * word 13 = the light's leaf position in the main triangle array.  Any pointer may be NULL. */
 int rt_flat_get_light_tree(const rt_flat *f, uint32_t info[2], float grid[6], uint32_t *nodes, float *recs);
+/* The main tree once more with up to four children per node, as the wavefront pipeline's trace kernel walks
+ * it (the other kernels walk the two-child nodes).  *nwide = node count; nodes: nwide * 12 words.  Child boxes
+ * are 8-bit in a frame of the node: per axis an origin on the node grid and a shift s, plane = grid_origin +
+ * (origin + (q << s)) * grid_cell.  Words 0-5 = lo.x, hi.x, lo.y, hi.y, lo.z, hi.z of children 0..3 (one byte
+ * each); word 6 = origin.x | origin.y << 16; word 7 = origin.z | s.x << 16 | s.y << 20 | s.z << 24 |
+ * children << 28; words 8-11 = child references (>= 0 index of a wide node, < 0 a leaf as in rt_flat_get,
+ * 0x7FFFFFFF unused).  Every child box contains the box the two-child tree holds for the same subtree. */
+int rt_flat_get_wide(const rt_flat *f, uint32_t *nwide, uint32_t *nodes);
 /* Quality of the main tree: the rt_scene_stats counter of splits the height bound overrode, and the
  * surface-area estimate of the work per random ray through the scene's bounds (expected node visits,
  * expected ray/triangle tests).  Any pointer may be NULL. */

@@ -66,6 +66,7 @@ SIGNATURES = {
     "rt_flat_build": (C.c_int, [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]),
     "rt_flat_get_light_tree": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_flat_get": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_flat_get_wide": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),
     "rt_flat_get_quality": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rt_flat_free": (None, [C.c_void_p]),
     "rt_intersect_rays": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

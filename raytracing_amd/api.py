@@ -109,7 +109,8 @@ def node_boxes(nodes, grid):
 
 def build_flat(host_scene):
     """Host-only acceleration-structure build (no GPU): returns dict(nodes (n,8) u32, grid (6,) f32,
-    tris (m,16) f32, lights (k,) u32 leaf-order positions, height, light_tree=dict(nodes, grid, recs (k,16), height))."""
+    tris (m,16) f32, lights (k,) u32 leaf-order positions, height, wide (w,12) u32 four-child nodes,
+    light_tree=dict(nodes, grid, recs (k,16), height))."""
     if isinstance(host_scene, dict):
         host_scene = HostScene(**host_scene)
     L = _lib.lib()
@@ -132,9 +133,13 @@ def build_flat(host_scene):
         check(L.rt_flat_get_light_tree(h, None, _p(lgrid), _p(lnodes), _p(lrecs) if lights.size else None))
         capped, sah_n, sah_t = C.c_uint32(), C.c_double(), C.c_double()
         check(L.rt_flat_get_quality(h, C.byref(capped), C.byref(sah_n), C.byref(sah_t)))
+        nwide = C.c_uint32()
+        check(L.rt_flat_get_wide(h, C.byref(nwide), None))
+        wide = np.empty((int(nwide.value), 12), dtype=np.uint32)
+        check(L.rt_flat_get_wide(h, None, _p(wide)))
     finally:
         L.rt_flat_free(h)
-    return dict(nodes=nodes, grid=grid, tris=tris, lights=lights, height=int(info[3]),
+    return dict(nodes=nodes, wide=wide, grid=grid, tris=tris, lights=lights, height=int(info[3]),
                 height_capped_splits=int(capped.value), sah_nodes=float(sah_n.value), sah_tris=float(sah_t.value),
                 light_tree=dict(nodes=lnodes, grid=lgrid, recs=lrecs, height=int(linfo[1])))
 

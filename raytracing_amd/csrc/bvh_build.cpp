@@ -647,6 +647,16 @@ int rt_flat_get_light_tree(const rt_flat *f, uint32_t info[2], float grid[6], ui
     return RT_OK;
 }
 
+int rt_flat_get_wide(const rt_flat *f, uint32_t *nwide, uint32_t *nodes) {
+    if (!f) {
+        rt::set_error("rt_flat_get_wide: null argument");
+        return RT_ERR_INVALID;
+    }
+    if (nwide) *nwide = f->flat.nwide;
+    if (nodes) std::memcpy(nodes, f->flat.wide.data(), f->flat.wide.size() * sizeof(uint32_t));
+    return RT_OK;
+}
+
 int rt_flat_get_quality(const rt_flat *f, uint32_t *height_capped_splits, double *sah_nodes, double *sah_tris) {
     if (!f) {
         rt::set_error("rt_flat_get_quality: null argument");

@@ -196,6 +196,53 @@ def _check_flat(flat, tri_verts, tri_material, materials):
     if nl:
         assert lwalk(0, 1) == lt["height"] <= 24 and (lseen[:nl] == 1).all()
 
+    # the four-child tree of the wavefront trace kernel: the same leaves, each exactly once; 2 to 4 children per
+    # node; every child box (8 bits per plane in the node's frame) contains the two-child tree's box of the
+    # same subtree -- checked against the box of every leaf below it, which the two-child tree was checked
+    # to hold the triangles in -- and is at most one frame step per side larger than the union of those
+    wide = flat["wide"]
+    grid = flat["grid"].astype(np.float64)
+    leafbox = {}
+    for node in range(nodes.shape[0]):
+        for side in range(2):
+            if refs[node, side] < 0 and not absent[node, side]:
+                leafbox[int(refs[node, side])] = boxes[node, side].astype(np.float64)
+    wseen = {}
+
+    def wwalk(node):
+        w = wide[node]
+        org = np.array([w[6] & 0xffff, w[6] >> 16, w[7] & 0xffff], dtype=np.float64)
+        sh = np.array([(w[7] >> 16) & 15, (w[7] >> 20) & 15, (w[7] >> 24) & 15])
+        nch = int(w[7] >> 28)
+        assert 2 <= nch <= 4
+        step = (2.0 ** sh) * grid[3:]
+        lo_all, hi_all = np.full(3, np.inf), np.full(3, -np.inf)
+        for c in range(4):
+            ref = int(np.int32(w[8 + c]))
+            if c >= nch:
+                assert ref == 0x7FFFFFFF
+                continue
+            ql = np.array([(w[0] >> 8 * c) & 255, (w[2] >> 8 * c) & 255, (w[4] >> 8 * c) & 255], dtype=np.float64)
+            qh = np.array([(w[1] >> 8 * c) & 255, (w[3] >> 8 * c) & 255, (w[5] >> 8 * c) & 255], dtype=np.float64)
+            assert (ql <= qh).all()
+            lo = grid[:3] + (org + ql * 2.0 ** sh) * grid[3:]
+            hi = grid[:3] + (org + qh * 2.0 ** sh) * grid[3:]
+            if ref < 0:
+                wseen[ref] = wseen.get(ref, 0) + 1
+                blo, bhi = leafbox[ref][:3], leafbox[ref][3:]
+            else:
+                blo, bhi = wwalk(ref)
+            tol = 1e-5 * np.maximum(np.abs(blo), np.abs(bhi)) + 1e-9       # float32 grid constants, float64 arithmetic here
+            assert (lo <= blo + tol).all() and (hi >= bhi - tol).all()
+            assert (lo >= blo - step - tol).all() and (hi <= bhi + step + tol).all()
+            lo_all, hi_all = np.minimum(lo_all, blo), np.maximum(hi_all, bhi)
+        return lo_all, hi_all
+
+    if n > 2:
+        wwalk(0)
+        assert sorted(wseen) == sorted(leafbox) and set(wseen.values()) == {1}
+        assert wide.shape[0] <= nodes.shape[0]
+
 
 @pytest.mark.parametrize("name,kw", [("cornell", {}), ("emissive", {"subdiv": 2, "lamps": 2}), ("heightfield100k", {"nx": 40, "nz": 40}),
                                      ("spheres1m", {"n_spheres": 10, "subdiv": 2, "ground": 8})])
