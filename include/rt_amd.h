@@ -264,7 +264,7 @@ int rt_render_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_beg
                   uint32_t max_depth, int rng_mode, uint32_t seed, int pipeline, float *d_radiance_sum,
                   void *stream);
 /* Scratch of the render calls (no reference counterpart: the CPU path keeps its state on the stack).
- * The wavefront pipeline keeps 82 bytes per path in flight (up to 64 frames of samples or 128 Mi
+ * The wavefront pipeline keeps 82 bytes per path in flight (up to 128 frames of samples or 256 Mi
  * paths, never more than spp_count frames), the reference-RNG mode 12 bytes per pixel and bounce.
  * rt_scene_reserve allocates them for the given call shape; buffers only grow and live until
  * rt_scene_destroy.  rt_render_dev on a scene whose scratch already covers the call only enqueues;

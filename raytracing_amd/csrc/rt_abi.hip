@@ -130,17 +130,17 @@ void free_wavefront(rt_scene *s) {
     w = rt::WavefrontBuffers();
 }
 
-// Path records in flight per wavefront pass: whole frames of samples, up to 64 of them or about 128M
-// paths (82 B each with the queues: 11 GB of the 288 GB), never more than the call renders.  The
+// Path records in flight per wavefront pass: whole frames of samples, up to 128 of them or about 256M
+// paths (82 B each with the queues: 22 GB of the 288 GB), never more than the call renders.  The
 // deeper bounces of a pass keep only a few percent of its paths alive, and every launch pays a ramp
 // and a drain of about one ray's duration, so fewer, larger launches win: 16M -> 3424, 32M -> 3656,
-// 64M -> 3763, 128M -> 3827 Mrays/s on the million-triangle 1080p depth-8 workload (4M: 1588 before
-// the other optimisations).  RT_WF_PATHS overrides the path budget.
+// 64M -> 3763, 128M -> 3827 Mrays/s on the million-triangle 1080p depth-8 workload in round 1; with
+// sorted rays 64M -> 5110, 128M -> 5229, 256M -> 5328, 512M -> 5342.  RT_WF_PATHS overrides the path budget.
 uint32_t wavefront_slots(uint32_t npix, uint32_t spp_count) {
-    uint64_t target = 128u << 20;
+    uint64_t target = 256u << 20;
     if (const char *e = std::getenv("RT_WF_PATHS")) target = std::strtoull(e, nullptr, 0);
     uint64_t slots = target / npix;
-    if (slots > 64) slots = 64;
+    if (slots > 128) slots = 128;
     if (slots > spp_count) slots = spp_count;
     if (slots < 1) slots = 1;
     return (uint32_t)slots;

@@ -408,49 +408,49 @@ def test_config5_glass_depth16(scene_dir, oracle_mod):
 
 
 def test_config5_full_size_properties_4k(scene_dir, oracle_mod):
-    """3840x2160, depth 16, the bench's glass scene (819 k triangles): at this size a pass holds 15
-    frames (1.24e8 path records), so 18 samples take two passes.  Checked through properties:
+    """3840x2160, depth 16, the bench's glass scene (819 k triangles): at this size a pass holds 32
+    frames (2.65e8 path records), so 36 samples take two passes.  Checked through properties:
     sample-range additivity, determinism, agreement of the two pipelines, and segment counts per
     sample consistent with the oracle's on the same scene at 1/12 size."""
     import raytracing_amd as rt
     W, H = 3840, 2160
     host, gpu, orc = _load(scene_dir, oracle_mod, "glass", W, H, grid=6, subdiv=5)
     gpu.reset_counters()
-    full = gpu.render(W, H, 18, max_depth=16, rng_mode=1, seed=8, pipeline=rt.PIPE_WAVEFRONT)
+    full = gpu.render(W, H, 36, max_depth=16, rng_mode=1, seed=8, pipeline=rt.PIPE_WAVEFRONT)
     segs = gpu.counters()["segments"]
     assert np.isfinite(full).all() and (full >= 0).all() and full.sum() > 0
-    a = gpu.render(W, H, 16, max_depth=16, rng_mode=1, seed=8, spp_begin=0, pipeline=rt.PIPE_WAVEFRONT)
-    b = gpu.render(W, H, 2, max_depth=16, rng_mode=1, seed=8, spp_begin=16, pipeline=rt.PIPE_WAVEFRONT)
+    a = gpu.render(W, H, 34, max_depth=16, rng_mode=1, seed=8, spp_begin=0, pipeline=rt.PIPE_WAVEFRONT)
+    b = gpu.render(W, H, 2, max_depth=16, rng_mode=1, seed=8, spp_begin=34, pipeline=rt.PIPE_WAVEFRONT)
     assert np.allclose(a + b, full, rtol=1e-5, atol=1e-6)
-    assert np.array_equal(full, gpu.render(W, H, 18, max_depth=16, rng_mode=1, seed=8, pipeline=rt.PIPE_WAVEFRONT))
-    mega = gpu.render(W, H, 2, max_depth=16, rng_mode=1, seed=8, spp_begin=16, pipeline=rt.PIPE_MEGAKERNEL)
+    assert np.array_equal(full, gpu.render(W, H, 36, max_depth=16, rng_mode=1, seed=8, pipeline=rt.PIPE_WAVEFRONT))
+    mega = gpu.render(W, H, 2, max_depth=16, rng_mode=1, seed=8, spp_begin=34, pipeline=rt.PIPE_MEGAKERNEL)
     assert np.allclose(mega, b, rtol=1e-5, atol=1e-6)
     _, c_small = orc.render(W // 12, H // 12, 4, max_depth=16, rng_mode=1, seed=8)
     per_small = c_small["segments"] / float((W // 12) * (H // 12) * 4)
-    assert abs(segs / float(W * H * 18) - per_small) < 0.03 * per_small
+    assert abs(segs / float(W * H * 36) - per_small) < 0.03 * per_small
 
 
 def test_cornell_1080p_more_samples_than_a_pass(scene_dir, oracle_mod):
-    """BASELINE config 3's frame (Cornell box, 1920x1080, depth 8) with 70 samples: more than the 64
+    """BASELINE config 3's frame (Cornell box, 1920x1080, depth 8) with 134 samples: more than the 128
     frames a pass holds, so the second pass runs.  Additivity over the pass boundary, determinism, and
     the mean image against the oracle's converged low-resolution render of the same view."""
     import raytracing_amd as rt
     W, H = 1920, 1080
     host, gpu, orc = _load(scene_dir, oracle_mod, "cornell", W, H)
-    full = gpu.render(W, H, 70, max_depth=8, rng_mode=1, seed=5, pipeline=rt.PIPE_WAVEFRONT)
-    a = gpu.render(W, H, 64, max_depth=8, rng_mode=1, seed=5, spp_begin=0, pipeline=rt.PIPE_WAVEFRONT)
-    b = gpu.render(W, H, 6, max_depth=8, rng_mode=1, seed=5, spp_begin=64, pipeline=rt.PIPE_WAVEFRONT)
+    full = gpu.render(W, H, 134, max_depth=8, rng_mode=1, seed=5, pipeline=rt.PIPE_WAVEFRONT)
+    a = gpu.render(W, H, 128, max_depth=8, rng_mode=1, seed=5, spp_begin=0, pipeline=rt.PIPE_WAVEFRONT)
+    b = gpu.render(W, H, 6, max_depth=8, rng_mode=1, seed=5, spp_begin=128, pipeline=rt.PIPE_WAVEFRONT)
     assert np.allclose(a + b, full, rtol=1e-5, atol=1e-6)
-    assert np.array_equal(full, gpu.render(W, H, 70, max_depth=8, rng_mode=1, seed=5, pipeline=rt.PIPE_WAVEFRONT))
+    assert np.array_equal(full, gpu.render(W, H, 134, max_depth=8, rng_mode=1, seed=5, pipeline=rt.PIPE_WAVEFRONT))
     assert np.isfinite(full).all() and (full >= 0).all()
-    # block means of the frame (8x8 pixels x 70 samples) against the oracle's 240x135 render at 128 spp
+    # block means of the frame (8x8 pixels x 134 samples) against the oracle's 240x135 render at 128 spp
     w, h = W // 8, H // 8
     small, _ = orc.render(w, h, 128, max_depth=8, rng_mode=1, seed=6)
-    blocks = full.reshape(h, 8, w, 8, 3).mean(axis=(1, 3)) / 70.0
+    blocks = full.reshape(h, 8, w, 8, 3).mean(axis=(1, 3)) / 134.0
     small = small.reshape(h, w, 3) / 128.0
     assert abs(blocks.mean() - small.mean()) < 0.02 * small.mean()
     # two independent 128-spp oracle renders of this view differ by 4 % in the median pixel; the GPU's
-    # 4480-sample blocks against one of them must do no worse (a structural error would)
+    # 8576-sample blocks against one of them must do no worse (a structural error would)
     assert np.median(np.abs(blocks - small) / np.maximum(small, 1e-3)) < 0.05
 
 
