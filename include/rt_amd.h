@@ -58,9 +58,9 @@ extern "C" {
 
 /* Pipelines of rt_render*: both produce the same estimator.
  * RT_PIPE_MEGAKERNEL: one persistent thread per pixel, a lane starts its next sample as soon
- * as its path ends.  RT_PIPE_WAVEFRONT: queue-per-bounce kernels (generate / trace / shade, and from the
- * second bounce on a regrouping of the ray queue by the cell of the ray origin) over 40-byte path records
- * and index queues; needs RT_RNG_COUNTER. */
+ * as its path ends.  RT_PIPE_WAVEFRONT: queue-per-bounce kernels (generate / trace / shade; optionally, from
+ * the second bounce on, a regrouping of the ray queue by the cell of the ray origin) over 40-byte path
+ * records and index queues; needs RT_RNG_COUNTER. */
 #define RT_PIPE_MEGAKERNEL 0
 #define RT_PIPE_WAVEFRONT 1
 

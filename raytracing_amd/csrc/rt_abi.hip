@@ -338,10 +338,10 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
     v.tan_y = desc->camera.tan_y;
     for (int k = 0; k < 3; ++k) v.bin_scale[k] = (float)(1u << rtd::kBinBits) / (65000.f * f.grid_cell[k]);
     {
-        // Regrouping the later bounces' rays by cell pays when the tree and triangles do not fit an XCD's
-        // 4 MB L2 (a 36-triangle box gains nothing and pays for the sort); RT_WF_SORT=0/1 overrides.
-        const size_t sceneBytes = (f.nodes.size() + f.tris.size()) * 4;
-        s->sort_rays = sceneBytes > (size_t)(4u << 20);
+        // Regrouping the later bounces' rays by cell (RT_WF_SORT=1) took a tenth off wf_extend while it walked
+        // the two-child tree; on the four-child tree it gains 5.6 % of wf_extend on the million-triangle scene
+        // and costs as much in sort kernels and scattered hits, and loses 7 % on the 4K glass frame: off unless asked for.
+        s->sort_rays = false;
         if (const char *e = std::getenv("RT_WF_SORT")) s->sort_rays = std::atoi(e) != 0;
         // RT_WF_WIDE=0: wf_extend walks the two-child tree; RT_WF_STACK_LIMIT=n (tests): the wide walk gives up
         // beyond n stack entries, which sends rays through the retry kernel
