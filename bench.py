@@ -188,6 +188,9 @@ def main():
         rec = rates["kernels"].get(kname) if rates.get("workload") == args.workload else None
         if rec:
             pmc_src = rates["source"]
+            # the counters are per launch of the PMC pass: scale them to this run's launch size
+            scale = segs_per_launch / rates["segments_per_launch"] if rates.get("segments_per_launch") else 1.0
+            rec = {k: (v * scale if k != "launches" else v) for k, v in rec.items()}
             traffic = rec.get("fabric_bytes")
             if traffic:
                 ceilings["hbm"] = {"achieved": round(traffic / launch_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s"}

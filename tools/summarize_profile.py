@@ -68,6 +68,13 @@ def main():
     # launch time it measures itself), and the gather rate of the vector-memory path from the
     # microbenchmark output committed next to them.
     rates = {"source": tag + "_pmc_summary.txt", "workload": workload, "kernels": {}}
+    # ray segments per wf_extend launch of the PMC passes (their bench line): bench.py scales the per-launch
+    # counters to the launch size it measures itself
+    plog = os.path.join(raw, "pmc1.log")
+    if os.path.exists(plog):
+        lines = [l for l in open(plog) if l.startswith("{")]
+        if lines:
+            rates["segments_per_launch"] = json.loads(lines[-1])["roofline"]["algorithmic"]["segments_per_launch"]
     want = {"TCP_TOTAL_CACHE_ACCESSES_sum": "l1_accesses", "SQ_INSTS_VALU": "valu_wave_insts",
             "SQ_INSTS_VMEM_RD": "vmem_rd_wave_insts", "SQ_INSTS_VMEM_WR": "vmem_wr_wave_insts",
             "GRBM_GUI_ACTIVE": "gui_active_cycles_sum_xcd", "TCP_TCC_READ_REQ_sum": "l1_misses_to_l2",
