@@ -5,8 +5,11 @@
 //   k_primary        camera ray of sample 0 per pixel + closest hit   (main.cpp:1212-1216, 1221)
 //   k_render_mega    persistent lane per pixel, path regeneration     (generatePixel's loop, main.cpp:1220-1225)
 //   k_render_replay  the reference's RNG stream and recursion order, bit-exact validation kernel
-//   wf_generate / wf_extend / wf_shade / wf_accumulate
-//                    the same estimator as queue-per-bounce kernels over 64-byte path records
+//   wf_generate / wf_extend (+ wf_extend_retry) / wf_shade / wf_accumulate
+//                    the same estimator as queue-per-bounce kernels over 40-byte path records; wf_extend
+//                    walks the four-child tree, everything else the two-child one
+//   wf_bin_hist / wf_bin_scan / wf_bin_scatter
+//                    optional regrouping of a ray queue by the cell of the ray origin (RT_WF_SORT=1)
 //   k_tonemap        mean, ACES, gamma, byte conversion               (main.cpp:1226-1231, 840-846)
 //
 // Pixel kernels map a wave to an 8x8 pixel tile (coherent primary rays) and a workgroup to a

@@ -84,7 +84,7 @@ static float area(const Box &b) {
 
 // mode 0: top-down greedy, largest child first, within the budget; mode 1: the same but a child is opened only
 // if its own two-child height is at most `low` (spend the budget near the leaves)
-static int g_mode = 0, g_low = 0, g_maxArity = 4;
+static int g_mode = 0, g_low = 0, g_maxArity = 4, g_order = 0;
 static long g_stackNeedMax = 0;
 
 static int32_t collapse(uint32_t node2, int budget, int used) {
@@ -194,8 +194,18 @@ static int trace4(const Ray &r, float &tBest, Counts &c) {
                 if (slab(w.box[k], r, inv, tBest, t)) tn[n] = t, idx[n++] = k;
             }
             if (n) {
-                for (int i = 1; i < n; ++i)  // insertion sort, nearest first
-                    for (int j = i; j > 0 && tn[j] < tn[j - 1]; --j) std::swap(tn[j], tn[j - 1]), std::swap(idx[j], idx[j - 1]);
+                if (g_order == 0) {
+                    for (int i = 1; i < n; ++i)  // insertion sort, nearest first
+                        for (int j = i; j > 0 && tn[j] < tn[j - 1]; --j) std::swap(tn[j], tn[j - 1]), std::swap(idx[j], idx[j - 1]);
+                } else {  // only the nearest is found; the others keep their storage order
+                    int m = 0;
+                    for (int i = 1; i < n; ++i)
+                        if (tn[i] < tn[m]) m = i;
+                    const float tm = tn[m];
+                    const int im = idx[m];
+                    for (int i = m; i > 0; --i) tn[i] = tn[i - 1], idx[i] = idx[i - 1];
+                    tn[0] = tm, idx[0] = im;
+                }
                 for (int i = n - 1; i >= 1; --i) stack[sp++] = w.ref[idx[i]];
                 c.maxsp = std::max<long>(c.maxsp, sp);
                 cur = w.ref[idx[0]];
@@ -290,9 +300,10 @@ int main(int argc, char **argv) {
         printf("\n");
     };
     report("two-child tree", false);
-    struct Cfg { const char *name; int mode, low, budget, arity; };
+    struct Cfg { const char *name; int mode, low, budget, arity, order; };
     const Cfg cfgs[] = {
         {"4-wide, no stack bound", 0, 0, 1000, 4},
+        {"4-wide, nearest first, rest in storage order", 0, 0, 1000, 4, 1},
         {"4-wide, budget 24 top-down", 0, 0, 24, 4},
         {"4-wide, budget 24, open h2<=6", 1, 6, 24, 4},
         {"4-wide, budget 24, open h2<=8", 1, 8, 24, 4},
@@ -304,7 +315,7 @@ int main(int argc, char **argv) {
     };
     for (const Cfg &cf : cfgs) {
         g_wide.clear();
-        g_mode = cf.mode, g_low = cf.low, g_maxArity = cf.arity;
+        g_mode = cf.mode, g_low = cf.low, g_maxArity = cf.arity, g_order = cf.order;
         g_stackNeedMax = 0;
         collapse(0, cf.budget, 0);
         double fill = 0;

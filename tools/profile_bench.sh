@@ -3,7 +3,7 @@
 #   bash tools/profile_bench.sh <round-tag> [extra bench.py args]
 # Pass 1: rocprofv3 --kernel-trace --stats of `python3 bench.py` (the command the driver runs).
 # Pass 2..: separate --pmc passes (FETCH_SIZE / WRITE_SIZE / cache and SQ counters) of a shorter run of
-# the same workload (128 spp = two passes of 64 frames of samples: the same launch sizes as the full run).
+# the same workload (128 spp = one pass of 128 frames of samples: the same launch sizes as the full run).
 # Raw output goes to gpurun_out/profile_<tag>/; tools/summarize_profile.py turns it into profiles/*.
 set -e
 tag=$1; shift
