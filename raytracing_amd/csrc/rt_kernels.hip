@@ -221,9 +221,10 @@ static_assert(2 * kBins == rt::kWfBinWords, "histogram + cursor buffer size");
 static_assert(kBins % kBlock == 0 && kBins <= 65536, "cells per thread in wf_bin_scan; cells are stored as 16 bits");
 
 // Path i's record is 40 bytes: 32 contiguous ones that hold the ray (what wf_extend reads) and 8 apart; a
-// lane moves it with two 16-byte and one 8-byte access.  It holds what the next bounce needs and nothing else.  The radiance a path has gathered lives apart (it changes
-// only when a path meets an emitter) and the depth left is the same for every path of a bounce, so
-// neither travels through the shading kernel's loads and stores.
+// lane moves it with two 16-byte and one 8-byte access.  It holds what the next bounce needs and nothing
+// else.  The radiance a path has gathered lives apart (it changes only when a path meets an emitter) and the
+// depth left is the same for every path of a bounce, so neither travels through the shading kernel's loads
+// and stores.  Before the first bounce a path is (d.xyz, bits(rng)) in lum[i] and nothing else: see wf_generate.
 struct WfView {
     float4 *ray;    // [2i] = (o.xyz, d.x)  [2i+1] = (d.y, d.z, throughput.x, throughput.y)
     float2 *c;      // [i] = (throughput.z, bits(rng))
@@ -252,10 +253,12 @@ __global__ __launch_bounds__(kBlock) void wf_generate(DevScene S, rt::RenderPara
         const uint32_t px = pix % rp.W, py = pix / rp.W;
         uint32_t rng = rng_seed(counter_seed(pix, sample, rp.seed));
         const v3 d = primary_direction(S, px, py, rp.W, rp.H, rng);
-        V.ray[2 * (size_t)i] = make_float4(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2], d.x);
-        V.ray[2 * (size_t)i + 1] = make_float4(d.y, d.z, 1.f, 1.f);
-        V.c[i] = make_float2(1.f, __uint_as_float(rng));
-        V.lum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // A camera ray's record is its direction and engine state: the origin is the camera's and the throughput
+        // is 1.  It lies where the path's radiance will: 16 bytes to write here instead of 56 (a record that is
+        // not a whole number of 32-byte sectors, or leaves gaps between records, costs more than it saves: 16 of
+        // every 32 bytes measured 5.1 ms where the 56 took 3.2).  The kernels of the first bounce know -- they are
+        // the ones launched without a queue -- and wf_shade then stores the radiance and the full record.
+        V.lum[i] = make_float4(d.x, d.y, d.z, __uint_as_float(rng));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         qcount[0] = npaths;
@@ -351,8 +354,13 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
                     const uint32_t qpos = chunkNext + (rank - given);
                     slot = queue ? queue[qpos] : qpos;
                     hitAt = hit_by_slot ? slot : qpos;  // dense 8-byte stores when wf_shade walks this same queue
-                    const float4 r0 = V.ray[2 * (size_t)slot], r1 = V.ray[2 * (size_t)slot + 1];
-                    T.start(S, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y));
+                    const float4 r0 = queue ? V.ray[2 * (size_t)slot] : V.lum[slot];
+                    if (queue) {
+                        const float4 r1 = V.ray[2 * (size_t)slot + 1];
+                        T.start(S, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y));
+                    } else {  // camera rays: (direction, engine state), see wf_generate
+                        T.start(S, mk(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]), mk(r0.x, r0.y, r0.z));
+                    }
                     hasRay = true;
                 }
                 chunkNext += take;
@@ -367,17 +375,23 @@ __global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const 
 // The rays wf_extend<WIDE> gave up on, one lane each, on the two-child tree (whose height bounds the stack).
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void wf_extend_retry(DevScene S, WfView V, const uint32_t *__restrict__ retry,
-                                                           const uint32_t *__restrict__ retry_count) {
+                                                           const uint32_t *__restrict__ retry_count, uint32_t camera_rays) {
     __shared__ int s_stack[kStack * kBlock];
     const uint32_t count = *retry_count;
     uint32_t segs = 0;
     TraceStats st{0, 0, 0, 0};
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < count; k += gridDim.x * kBlock) {
         const uint32_t slot = retry[2 * (size_t)k], hitAt = retry[2 * (size_t)k + 1];
-        const float4 r0 = V.ray[2 * (size_t)slot], r1 = V.ray[2 * (size_t)slot + 1];
+        const float4 r0 = camera_rays ? V.lum[slot] : V.ray[2 * (size_t)slot];
+        v3 o = mk(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]), d = mk(r0.x, r0.y, r0.z);  // see wf_generate
+        if (!camera_rays) {
+            const float4 r1 = V.ray[2 * (size_t)slot + 1];
+            o = mk(r0.x, r0.y, r0.z);
+            d = mk(r0.w, r1.x, r1.y);
+        }
         float t;
         int tri;
-        closest_hit<COUNT>(S, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), s_stack + threadIdx.x, t, tri, st);
+        closest_hit<COUNT>(S, o, d, s_stack + threadIdx.x, t, tri, st);
         V.hit[hitAt] = make_float2(t, __int_as_float(tri));
         ++segs;
     }
@@ -436,19 +450,30 @@ __global__ __launch_bounds__(kBlock, TREE ? 1 : 6) void wf_shade(DevScene S, WfV
         uint32_t cell = 0;
         if (j < count) {
             const float2 h = V.hit[hit_by_slot ? i : j];
-            const float4 r0 = V.ray[2 * (size_t)i], r1 = V.ray[2 * (size_t)i + 1];
-            const float2 r2 = V.c[i];
+            const float4 r0 = queue ? V.ray[2 * (size_t)i] : V.lum[i];
             const uint32_t jn = j + stride;
-            if (jn < count) iNext = queue ? queue[jn] : jn;
             PathState P;
-            P.o = mk(r0.x, r0.y, r0.z);
-            P.d = mk(r0.w, r1.x, r1.y);
-            P.T = mk(r1.z, r1.w, r2.x);
+            if (queue) {
+                const float4 r1 = V.ray[2 * (size_t)i + 1];
+                const float2 r2 = V.c[i];
+                if (jn < count) iNext = queue[jn];
+                P.o = mk(r0.x, r0.y, r0.z);
+                P.d = mk(r0.w, r1.x, r1.y);
+                P.T = mk(r1.z, r1.w, r2.x);
+                P.rng = __float_as_uint(r2.y);
+            } else {  // camera rays: (direction, engine state), see wf_generate
+                if (jn < count) iNext = jn;
+                P.o = mk(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]);
+                P.d = mk(r0.x, r0.y, r0.z);
+                P.T = mk(1.f, 1.f, 1.f);
+                P.rng = __float_as_uint(r0.w);
+            }
             P.L = mk(0.f, 0.f, 0.f);
-            P.rng = __float_as_uint(r2.y);
             P.depth = depth;  // rayDepth of every hit of this bounce (main.cpp:1188-1199)
             alive = shade_hit<TREE>(S, LC, P, h.x, __float_as_int(h.y), lightTests);
-            if (P.L.x != 0.f || P.L.y != 0.f || P.L.z != 0.f) {  // the path met an emitter (or went NaN): 0 + x == x, so
+            if (!queue) {  // first bounce: the camera record makes way for the radiance
+                V.lum[i] = make_float4(P.L.x, P.L.y, P.L.z, 0.f);
+            } else if (P.L.x != 0.f || P.L.y != 0.f || P.L.z != 0.f) {  // the path met an emitter (or went NaN): 0 + x == x, so
                 const float4 l = V.lum[i];                        // the stored sum is what a carried one would be
                 V.lum[i] = make_float4(l.x + P.L.x, l.y + P.L.y, l.z + P.L.z, 0.f);
             }
@@ -720,7 +745,7 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
                                retry, retryCount, wb.stack_limit, (qs != qu) ? 1u : 0u);
             if (wb.wide)
                 hipLaunchKernelGGL(count ? wf_extend_retry<true> : wf_extend_retry<false>, dim3(kRetryGrid), dim3(kBlock), 0, stream, S,
-                                   V, retry, retryCount);
+                                   V, retry, retryCount, b == 0 ? 1u : 0u);
             timer.end(stream);
             timer.begin(kKernShade, stream);
             hipLaunchKernelGGL(S.light_tree ? wf_shade<true> : wf_shade<false>, dim3(grid), dim3(kBlock), 0, stream, S, V,
