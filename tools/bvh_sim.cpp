@@ -85,6 +85,27 @@ static float area(const Box &b) {
 // mode 0: top-down greedy, largest child first, within the budget; mode 1: the same but a child is opened only
 // if its own two-child height is at most `low` (spend the budget near the leaves)
 static int g_mode = 0, g_low = 0, g_maxArity = 4, g_order = 0;
+static int g_qbits = 0;  // > 0: child boxes re-quantised to this many bits in a frame of the node (origin + shift per axis)
+
+static void requantise(WNode &w) {
+    const uint32_t top = (1u << g_qbits) - 1u;
+    for (int a = 0; a < 3; ++a) {
+        uint32_t lo[4], hi[4], mn = 65535u, mx = 0u;
+        for (int c = 0; c < w.n; ++c) {
+            lo[c] = (uint32_t)std::lround((w.box[c].lo[a] - g_grid[a]) / g_grid[3 + a]);
+            hi[c] = (uint32_t)std::lround((w.box[c].hi[a] - g_grid[a]) / g_grid[3 + a]);
+            mn = std::min(mn, lo[c]);
+            mx = std::max(mx, hi[c]);
+        }
+        uint32_t s = 0;
+        while (((mx - mn + (1u << s) - 1u) >> s) > top) ++s;
+        for (int c = 0; c < w.n; ++c) {
+            uint32_t ql = (lo[c] - mn) >> s, qh = (hi[c] - mn + (1u << s) - 1u) >> s;
+            w.box[c].lo[a] = g_grid[a] + (float)(mn + (ql << s)) * g_grid[3 + a];
+            w.box[c].hi[a] = g_grid[a] + (float)(mn + (qh << s)) * g_grid[3 + a];
+        }
+    }
+}
 static long g_stackNeedMax = 0;
 
 static int32_t collapse(uint32_t node2, int budget, int used) {
@@ -119,6 +140,7 @@ static int32_t collapse(uint32_t node2, int budget, int used) {
         ++w.n;
     }
     g_stackNeedMax = std::max<long>(g_stackNeedMax, used + w.n - 1);
+    if (g_qbits) requantise(w);
     int32_t id = (int32_t)g_wide.size();
     g_wide.push_back(w);
     for (int c = 0; c < w.n; ++c)
@@ -300,9 +322,13 @@ int main(int argc, char **argv) {
         printf("\n");
     };
     report("two-child tree", false);
-    struct Cfg { const char *name; int mode, low, budget, arity, order; };
+    struct Cfg { const char *name; int mode, low, budget, arity, order, qbits; };
     const Cfg cfgs[] = {
         {"4-wide, no stack bound", 0, 0, 1000, 4},
+        {"4-wide, 8-bit boxes in a node frame", 0, 0, 1000, 4, 0, 8},
+        {"4-wide, 7-bit boxes in a node frame", 0, 0, 1000, 4, 0, 7},
+        {"4-wide, 6-bit boxes in a node frame", 0, 0, 1000, 4, 0, 6},
+        {"4-wide, 5-bit boxes in a node frame", 0, 0, 1000, 4, 0, 5},
         {"4-wide, nearest first, rest in storage order", 0, 0, 1000, 4, 1},
         {"4-wide, budget 24 top-down", 0, 0, 24, 4},
         {"4-wide, budget 24, open h2<=6", 1, 6, 24, 4},
@@ -315,7 +341,7 @@ int main(int argc, char **argv) {
     };
     for (const Cfg &cf : cfgs) {
         g_wide.clear();
-        g_mode = cf.mode, g_low = cf.low, g_maxArity = cf.arity, g_order = cf.order;
+        g_mode = cf.mode, g_low = cf.low, g_maxArity = cf.arity, g_order = cf.order, g_qbits = cf.qbits;
         g_stackNeedMax = 0;
         collapse(0, cf.budget, 0);
         double fill = 0;
