@@ -411,10 +411,14 @@ constexpr uint32_t kAppendBuf = 2048;  // LDS entries per workgroup (8 KB + 4 KB
 // workgroups still fit a CU (with the full one only three did: 89.8 -> 109 ms on the 15 360-light frame).
 constexpr uint32_t kAppendBufTree = 1024;
 
-// Six waves per SIMD (at most 80 VGPRs): left alone the compiler takes 83 and a wave less; no spills (-2 %).
+// Eight waves per SIMD (64 VGPRs, eight 19.7 KB workgroups in a CU's LDS).  Left alone the compiler takes 83
+// registers and five waves; bounded to six (80, no spills) the kernel ran 2 % faster, and at eight -- ten
+// registers spilled, in the flush path -- another 3 % (27.7 vs 28.6 ms per 128-sample pass of the million-
+// triangle frame; seven waves are slower than six).  Half its time the kernel waits for records and triangles.
 // (Not the light-tree variant: its stack in LDS bounds it to fewer waves anyway.)
+constexpr int kShadeWaves = 8;
 template <bool TREE>
-__global__ __launch_bounds__(kBlock, TREE ? 1 : 6) void wf_shade(DevScene S, WfView V, const uint32_t *__restrict__ queue,
+__global__ __launch_bounds__(kBlock, TREE ? 1 : kShadeWaves) void wf_shade(DevScene S, WfView V, const uint32_t *__restrict__ queue,
                                                     const uint32_t *__restrict__ qcount_in,
                                                     uint32_t *__restrict__ queue_out, uint32_t *__restrict__ qcount_out,
                                                     uint32_t *__restrict__ cursors, uint32_t depth, uint32_t want_bins,
