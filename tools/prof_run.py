@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--count", action="store_true")
+    ap.add_argument("--grow-spp", type=int, default=0, help="render this many samples once first (sizes the path buffers)")
     a = ap.parse_args()
 
     import torch
@@ -51,6 +52,11 @@ def main():
             scene.render_dev(W, H, a.spp, buf.data_ptr(), max_depth=a.depth, rng_mode=rt.RNG_COUNTER, seed=1,
                              pipeline=rt.PIPE_MEGAKERNEL if a.pipeline == "mega" else rt.PIPE_WAVEFRONT, stream=stream)
 
+    if a.grow_spp:
+        spp, a.spp = a.spp, a.grow_spp
+        launch()
+        torch.cuda.synchronize()
+        a.spp = spp
     launch()
     torch.cuda.synchronize()
     scene.reset_counters(stream)
