@@ -59,7 +59,7 @@ extern "C" {
 /* Pipelines of rt_render*: both produce the same estimator.
  * RT_PIPE_MEGAKERNEL: one persistent thread per pixel, a lane starts its next sample as soon
  * as its path ends.  RT_PIPE_WAVEFRONT: queue-per-bounce kernels (generate / trace / shade; optionally, from
- * the second bounce on, a regrouping of the ray queue by the cell of the ray origin) over 40-byte path
+ * the second bounce on, a regrouping of the ray queue by the cell of the ray origin) over 48-byte path
  * records and index queues; needs RT_RNG_COUNTER. */
 #define RT_PIPE_MEGAKERNEL 0
 #define RT_PIPE_WAVEFRONT 1
@@ -264,7 +264,7 @@ int rt_render_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_beg
                   uint32_t max_depth, int rng_mode, uint32_t seed, int pipeline, float *d_radiance_sum,
                   void *stream);
 /* Scratch of the render calls (no reference counterpart: the CPU path keeps its state on the stack).
- * The wavefront pipeline keeps 82 bytes per path in flight (up to 128 frames of samples or 256 Mi
+ * The wavefront pipeline keeps 90 bytes per path in flight (up to 128 frames of samples or 256 Mi
  * paths, never more than spp_count frames), the reference-RNG mode 12 bytes per pixel and bounce.
  * rt_scene_reserve allocates them for the given call shape; buffers only grow and live until
  * rt_scene_destroy.  rt_render_dev on a scene whose scratch already covers the call only enqueues;
@@ -276,7 +276,7 @@ int rt_scene_reserve(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_
  * capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.
  * Same estimator, kernels and results as rt_render_dev(..., RT_RNG_COUNTER, seed, RT_PIPE_WAVEFRONT, ...)
  * (bit-identical sums), but the path records, queues and cursors live in a fixed array inside the
- * library's code object (172 MB per GPU, held from the library's first launch on that GPU until the
+ * library's code object (189 MB per GPU, held from the library's first launch on that GPU until the
  * process ends) instead of scene-owned allocations, and the call makes no hipMalloc / hipFree.
  * Limit: width * height <= RT_NOALLOC_MAX_PIXELS (one 1920x1080 frame fits), RT_ERR_LIMIT beyond;
  * smaller images keep up to 64 frames of samples in flight.  Every call on a GPU shares that GPU's

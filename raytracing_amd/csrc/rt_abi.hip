@@ -24,14 +24,14 @@ void set_error(const std::string &msg) { g_error = msg; }
 // Path records, index queues, queue counters and work cursors of the wavefront pipeline for
 // kNoAllocPaths paths in flight, laid out back to back in one array that is part of the library's code
 // object: every GPU the library runs on holds its own copy from the first launch on that GPU until the
-// process ends (172 MB).  Host code must not use the array's name as an address: the address on a
+// process ends (189 MB).  Host code must not use the array's name as an address: the address on a
 // given GPU comes from hipGetSymbolAddress with that GPU current (scratch_of below).
 namespace {
 constexpr uint32_t kNoAllocPaths = RT_NOALLOC_MAX_PIXELS;  // one path per pixel at least
 constexpr size_t kScratchRay = 0;                                             // float4[2 * paths]
 constexpr size_t kScratchLum = kScratchRay + (size_t)kNoAllocPaths * 32;      // float4[paths]
-constexpr size_t kScratchC = kScratchLum + (size_t)kNoAllocPaths * 16;        // float2[paths]
-constexpr size_t kScratchHit = kScratchC + (size_t)kNoAllocPaths * 8;         // float2[paths]
+constexpr size_t kScratchC = kScratchLum + (size_t)kNoAllocPaths * 16;        // float4[paths]
+constexpr size_t kScratchHit = kScratchC + (size_t)kNoAllocPaths * 16;        // float2[paths]
 constexpr size_t kScratchQueue0 = kScratchHit + (size_t)kNoAllocPaths * 8;    // uint32_t[paths]
 constexpr size_t kScratchQueue1 = kScratchQueue0 + (size_t)kNoAllocPaths * 4; // uint32_t[paths]
 constexpr size_t kScratchRetry = kScratchQueue1 + (size_t)kNoAllocPaths * 4; // uint32_t[2 * paths]
@@ -131,7 +131,7 @@ void free_wavefront(rt_scene *s) {
 }
 
 // Path records in flight per wavefront pass: whole frames of samples, up to 128 of them or about 256M
-// paths (82 B each with the queues: 22 GB of the 288 GB), never more than the call renders.  The
+// paths (90 B each with the queues: 24 GB of the 288 GB), never more than the call renders.  The
 // deeper bounces of a pass keep only a few percent of its paths alive, and every launch pays a ramp
 // and a drain of about one ray's duration, so fewer, larger launches win: 16M -> 3424, 32M -> 3656,
 // 64M -> 3763, 128M -> 3827 Mrays/s on the million-triangle 1080p depth-8 workload in round 1; with
@@ -533,7 +533,7 @@ int rt_render_noalloc_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t
     rt::WavefrontBuffers wb;
     wb.capacity = kNoAllocPaths;
     wb.ray = reinterpret_cast<float4 *>(base + kScratchRay);
-    wb.c = reinterpret_cast<float2 *>(base + kScratchC);
+    wb.c = reinterpret_cast<float4 *>(base + kScratchC);
     wb.lum = reinterpret_cast<float4 *>(base + kScratchLum);
     wb.hit = reinterpret_cast<float2 *>(base + kScratchHit);
     wb.queue[0] = reinterpret_cast<uint32_t *>(base + kScratchQueue0);

@@ -6,7 +6,7 @@
 //   k_render_mega    persistent lane per pixel, path regeneration     (generatePixel's loop, main.cpp:1220-1225)
 //   k_render_replay  the reference's RNG stream and recursion order, bit-exact validation kernel
 //   wf_generate / wf_extend (+ wf_extend_retry) / wf_shade / wf_accumulate
-//                    the same estimator as queue-per-bounce kernels over 40-byte path records; wf_extend
+//                    the same estimator as queue-per-bounce kernels over 48-byte path records; wf_extend
 //                    walks the four-child tree, everything else the two-child one
 //   wf_bin_hist / wf_bin_scan / wf_bin_scatter
 //                    optional regrouping of a ray queue by the cell of the ray origin (RT_WF_SORT=1)
@@ -220,15 +220,17 @@ static_assert(kShards * kCursorStride == rt::kWfCursorWords, "cursor buffer size
 static_assert(2 * kBins == rt::kWfBinWords, "histogram + cursor buffer size");
 static_assert(kBins % kBlock == 0 && kBins <= 65536, "cells per thread in wf_bin_scan; cells are stored as 16 bits");
 
-// Path i's record is 40 bytes: 32 contiguous ones that hold the ray (what wf_extend reads) and 8 apart; a
-// lane moves it with two 16-byte and one 8-byte access.  It holds what the next bounce needs and nothing
-// else.  The radiance a path has gathered lives apart (it changes only when a path meets an emitter) and the
-// depth left is the same for every path of a bounce, so neither travels through the shading kernel's loads
-// and stores.  Before the first bounce a path is (d.xyz, bits(rng)) in lum[i] and nothing else: see wf_generate.
+// The record in slot i is 48 bytes: 32 contiguous ones that hold the ray (what wf_extend reads) and 16 apart; a
+// lane moves it with three 16-byte accesses.  It holds what the next bounce needs and nothing else.  The
+// radiance a path has gathered lives apart, at the slot the path started in (its home slot: that is the pixel
+// and sample it belongs to), and changes only when the path meets an emitter; the depth left is the same for
+// every path of a bounce; so neither travels through the shading kernel's loads and stores.  Records do not
+// keep their slots: wf_shade moves the survivors of every wave together (see there).  Before the first bounce
+// a path is (d.xyz, bits(rng)) in lum[i] and nothing else: see wf_generate.
 struct WfView {
     float4 *ray;    // [2i] = (o.xyz, d.x)  [2i+1] = (d.y, d.z, throughput.x, throughput.y)
-    float2 *c;      // [i] = (throughput.z, bits(rng))
-    float4 *lum;    // [i] = (radiance gathered so far .xyz, 0)
+    float4 *c;      // [i] = (throughput.z, bits(rng), bits(home slot), 0)
+    float4 *lum;    // [home slot] = (radiance gathered so far .xyz, 0)
     float2 *hit;    // (hit t, bits(hit triangle)) of a path's current ray: at its queue position, or at its slot when
                     // the queue wf_extend traces is a regrouped copy of the one wf_shade walks (hit_by_slot)
     uint16_t *bin;  // [j] = ray-sorting cell of the ray at position j of the queue wf_shade is filling
@@ -411,12 +413,12 @@ constexpr uint32_t kAppendBuf = 2048;  // LDS entries per workgroup (8 KB + 4 KB
 // workgroups still fit a CU (with the full one only three did: 89.8 -> 109 ms on the 15 360-light frame).
 constexpr uint32_t kAppendBufTree = 1024;
 
-// Eight waves per SIMD (64 VGPRs, eight 19.7 KB workgroups in a CU's LDS).  Left alone the compiler takes 83
-// registers and five waves; bounded to six (80, no spills) the kernel ran 2 % faster, and at eight -- ten
-// registers spilled, in the flush path -- another 3 % (27.7 vs 28.6 ms per 128-sample pass of the million-
-// triangle frame; seven waves are slower than six).  Half its time the kernel waits for records and triangles.
+// Six waves per SIMD (80 VGPRs, no spills).  Left alone the compiler takes 83 registers and five waves (+2 %).
+// At eight waves (64 VGPRs) the kernel spills 16 registers since it carries the home slot and moves the survivors:
+// 29.7 instead of 26.0 ms per 128-sample pass of the million-triangle frame (before the survivors moved, eight
+// waves with ten spills had been the best: 27.5 ms).
 // (Not the light-tree variant: its stack in LDS bounds it to fewer waves anyway.)
-constexpr int kShadeWaves = 8;
+constexpr int kShadeWaves = 6;
 template <bool TREE>
 __global__ __launch_bounds__(kBlock, TREE ? 1 : kShadeWaves) void wf_shade(DevScene S, WfView V, const uint32_t *__restrict__ queue,
                                                     const uint32_t *__restrict__ qcount_in,
@@ -451,20 +453,22 @@ __global__ __launch_bounds__(kBlock, TREE ? 1 : kShadeWaves) void wf_shade(DevSc
     for (uint32_t r = 0; r < rounds; ++r, j += stride) {
         bool alive = false;
         const uint32_t i = iNext;
-        uint32_t cell = 0;
+        uint32_t cell = 0, home = i;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
         if (j < count) {
             const float2 h = V.hit[hit_by_slot ? i : j];
-            const float4 r0 = queue ? V.ray[2 * (size_t)i] : V.lum[i];
+            r0 = queue ? V.ray[2 * (size_t)i] : V.lum[i];
             const uint32_t jn = j + stride;
             PathState P;
             if (queue) {
-                const float4 r1 = V.ray[2 * (size_t)i + 1];
-                const float2 r2 = V.c[i];
+                r1 = V.ray[2 * (size_t)i + 1];
+                r2 = V.c[i];
                 if (jn < count) iNext = queue[jn];
                 P.o = mk(r0.x, r0.y, r0.z);
                 P.d = mk(r0.w, r1.x, r1.y);
                 P.T = mk(r1.z, r1.w, r2.x);
                 P.rng = __float_as_uint(r2.y);
+                home = __float_as_uint(r2.z);
             } else {  // camera rays: (direction, engine state), see wf_generate
                 if (jn < count) iNext = jn;
                 P.o = mk(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]);
@@ -476,27 +480,37 @@ __global__ __launch_bounds__(kBlock, TREE ? 1 : kShadeWaves) void wf_shade(DevSc
             P.depth = depth;  // rayDepth of every hit of this bounce (main.cpp:1188-1199)
             alive = shade_hit<TREE>(S, LC, P, h.x, __float_as_int(h.y), lightTests);
             if (!queue) {  // first bounce: the camera record makes way for the radiance
-                V.lum[i] = make_float4(P.L.x, P.L.y, P.L.z, 0.f);
+                V.lum[home] = make_float4(P.L.x, P.L.y, P.L.z, 0.f);
             } else if (P.L.x != 0.f || P.L.y != 0.f || P.L.z != 0.f) {  // the path met an emitter (or went NaN): 0 + x == x, so
-                const float4 l = V.lum[i];                        // the stored sum is what a carried one would be
-                V.lum[i] = make_float4(l.x + P.L.x, l.y + P.L.y, l.z + P.L.z, 0.f);
+                const float4 l = V.lum[home];                     // the stored sum is what a carried one would be
+                V.lum[home] = make_float4(l.x + P.L.x, l.y + P.L.y, l.z + P.L.z, 0.f);
             }
             if (alive) {
-                V.ray[2 * (size_t)i] = make_float4(P.o.x, P.o.y, P.o.z, P.d.x);
-                V.ray[2 * (size_t)i + 1] = make_float4(P.d.y, P.d.z, P.T.x, P.T.y);
-                V.c[i] = make_float2(P.T.z, __uint_as_float(P.rng));
+                r0 = make_float4(P.o.x, P.o.y, P.o.z, P.d.x);
+                r1 = make_float4(P.d.y, P.d.z, P.T.x, P.T.y);
+                r2 = make_float4(P.T.z, __uint_as_float(P.rng), __uint_as_float(home), 0.f);
                 if (want_bins) cell = ray_bin(S, P.o);
             }
         }
+        // The survivors of a wave's 64 paths move to the first of the wave's 64 slots (a wave has read all its
+        // records before it stores any): the paths still alive after some bounces would otherwise lie scattered
+        // over the slots they started in, every record costing whole lines to read and masked lines to
+        // write.  Runs of slots stay runs: the next bounce's waves read the queue in the order written here.
         const unsigned long long mask = __ballot(alive);
         if (mask) {
             const int leader = __builtin_ctzll(mask);
             uint32_t base = 0;
             if (lane == (uint32_t)leader) base = atomicAdd(&s_count, (uint32_t)__builtin_popcountll(mask));
             base = __shfl(base, leader);
+            const uint32_t rank = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            // lane `rank` holds a path of this round: survivors <= paths, and the paths fill the low lanes
+            const uint32_t to = __shfl(i, (int)rank);
             if (alive) {
-                const uint32_t at = base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-                s_buf[at] = i;
+                const uint32_t at = base + rank;
+                V.ray[2 * (size_t)to] = r0;
+                V.ray[2 * (size_t)to + 1] = r1;
+                V.c[to] = r2;
+                s_buf[at] = to;
                 s_bin[at] = (uint16_t)cell;
             }
         }

@@ -79,18 +79,18 @@ struct RenderParams {
     uint32_t seed;
 };
 
-// Scratch of the wavefront pipeline for `capacity` paths in flight, 82 bytes per path: a 40-byte record
-// (32 contiguous bytes of ray + 8 apart; two 16-byte and one 8-byte access per lane: the vector-memory
-// path charges per lane and instruction, the memory system per sector), the radiance gathered so far, the hit of the
-// bounce being traced, two index queues, the retry list of the wide walk and the ray-sorting cells; plus queue counters, work cursors and the cell histogram.  Owned by the scene,
-// grown on demand.
+// Scratch of the wavefront pipeline for `capacity` paths in flight, 90 bytes per path: a 48-byte record
+// (32 contiguous bytes of ray + 16 apart; three 16-byte accesses per lane: the vector-memory path charges per
+// lane and instruction, the memory system per sector), the radiance gathered so far, the hit of the bounce
+// being traced, two index queues, the retry list of the wide walk and the ray-sorting cells; plus queue
+// counters, work cursors and the cell histogram.  Owned by the scene, grown on demand.
 constexpr size_t kWfCursorWords = 8 * 1024;  // 8 cursors, 4 KB apart (rt_kernels.hip: kShards x kCursorStride)
 constexpr size_t kWfBinWords = 2 * 4096;     // histogram + cursors of the ray-sorting cells (rt_device.h: kBins)
-constexpr size_t kWfBytesPerPath = 16 + 16 + 8 + 16 + 8 + 4 + 4 + 8 + 2;
+constexpr size_t kWfBytesPerPath = 16 + 16 + 16 + 16 + 8 + 4 + 4 + 8 + 2;
 struct WavefrontBuffers {
     uint32_t capacity = 0;
     float4 *ray = nullptr;    // 2 x capacity: [2i] = (o.xyz, d.x)  [2i+1] = (d.y, d.z, throughput.x, throughput.y)
-    float2 *c = nullptr;      // capacity: (throughput.z, bits(rng))
+    float4 *c = nullptr;      // capacity: (throughput.z, bits(rng), bits(home slot), 0)
     float4 *lum = nullptr;    // capacity: (radiance gathered so far .xyz, 0)
     float2 *hit = nullptr;    // capacity: (hit t, bits(hit triangle)) of each path's current ray
     uint32_t *queue[2] = {nullptr, nullptr};  // path indices alive in the current / next bounce, in append order or regrouped by cell

@@ -372,11 +372,11 @@ def test_scratch_is_grow_only_and_sized_by_the_call(scene_dir, oracle_mod):
     W, H = 64, 48
     host, gpu, orc = _load(scene_dir, oracle_mod, "cornell", W, H)
     base = gpu.stats()["device_bytes"]
-    per_frame = W * H * 82
+    per_frame = W * H * 90
     fixed = 70000                                         # counters, work cursors, cell histogram
     gpu.render(W, H, 1, rng_mode=1, pipeline=rt.PIPE_WAVEFRONT)
     b1 = gpu.stats()["device_bytes"] - base
-    assert per_frame <= b1 < per_frame + fixed            # one frame of 82 bytes per path
+    assert per_frame <= b1 < per_frame + fixed            # one frame of 90 bytes per path
     gpu.reserve(W, H, 5, pipeline=rt.PIPE_WAVEFRONT)
     b5 = gpu.stats()["device_bytes"] - base
     assert 5 * per_frame <= b5 < 5 * per_frame + fixed
