@@ -405,10 +405,11 @@ __global__ __launch_bounds__(kBlock) void wf_extend_retry(DevScene S, WfView V, 
 // microsecond however many CUs issue them: with one global atomic per wave and round this kernel
 // (and through its work cursor, wf_extend) ran at exactly that rate -- 1.65 M atomics = 17 ms per
 // 16-spp pass of the 1080p Cornell frame.  Survivors are first collected in an LDS buffer of the
-// workgroup (one LDS atomic per wave and round, lanes write at their ballot-prefix offset); when the
-// buffer is nearly full, and after the last round, the workgroup reserves space in the global
-// queue with ONE atomic and copies the buffer out with coalesced stores.
-constexpr uint32_t kAppendBuf = 2048;  // LDS entries per workgroup (8 KB + 4 KB of cells); flushed above kAppendBuf - kBlock
+// workgroup (one LDS atomic per wave and round, lanes write at their ballot-prefix offset); every few
+// rounds, and after the last one, the workgroup reserves space in the global queue with ONE atomic and
+// copies the buffer out with coalesced stores.
+constexpr uint32_t kAppendBuf = 3072;        // LDS entries per workgroup (12 KB + 6 KB of cells): six workgroups per CU
+constexpr uint32_t kAppendBufCamera = 2048;  // the camera-ray instantiation runs eight workgroups per CU
 // The light-tree variant keeps a 24 KB traversal stack in LDS as well: with half the buffer four of its
 // workgroups still fit a CU (with the full one only three did: 89.8 -> 109 ms on the 15 360-light frame).
 constexpr uint32_t kAppendBufTree = 1024;
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(kBlock, TREE ? 1 : (CAMERA ? kShadeWavesCamera : kS
                                                     uint32_t *__restrict__ queue_out, uint32_t *__restrict__ qcount_out,
                                                     uint32_t *__restrict__ cursors, uint32_t depth, uint32_t want_bins,
                                                     uint32_t *__restrict__ retry_count, uint32_t hit_by_slot) {
-    constexpr uint32_t kBuf = TREE ? kAppendBufTree : kAppendBuf;
+    constexpr uint32_t kBuf = TREE ? kAppendBufTree : CAMERA ? kAppendBufCamera : kAppendBuf;
     const uint32_t *__restrict__ queue = CAMERA ? nullptr : queue_;  // camera rays: the identity queue
     __shared__ uint32_t s_buf[kBuf];
     __shared__ uint16_t s_bin[kBuf];
@@ -518,9 +519,13 @@ __global__ __launch_bounds__(kBlock, TREE ? 1 : (CAMERA ? kShadeWavesCamera : kS
                 s_bin[at] = (uint16_t)cell;
             }
         }
-        __syncthreads();
-        const uint32_t n = s_count;
-        if (n > kBuf - kBlock || (r + 1 == rounds && n)) {  // uniform: every thread read the same s_count
+        // The buffer holds kFlushRounds rounds whatever survives, so the rounds between two flushes need no
+        // barrier and the workgroup's waves drift apart by as much (a barrier per round, to decide the flush by
+        // the buffer's fill, cost 2.4 % of the kernel).
+        constexpr uint32_t kFlushRounds = kBuf / kBlock - 1u;
+        if (r % kFlushRounds == kFlushRounds - 1u || r + 1 == rounds) {
+            __syncthreads();
+            const uint32_t n = s_count;
             if (threadIdx.x == 0) s_base = atomicAdd(qcount_out, n);
             __syncthreads();
             const uint32_t gbase = s_base;
