@@ -16,7 +16,7 @@ for f in glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
         for s in ("wf_extend", "wf_shade", "wf_generate", "wf_accumulate"):
-            if s in n:
+            if s in n and "retry" not in n:
                 rows.append((int(r["Start_Timestamp"]), s, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6))
 rows.sort()
 # last render = after the last wf_generate
