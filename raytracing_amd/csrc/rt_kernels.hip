@@ -289,16 +289,24 @@ constexpr int kRefill = 20;  // 4: -3 %, 12: -1 %, 16 to 24: within 0.5 %, 32: -
 // with the fold compiled into the one kernel, scenes without primitives traced 12 % slower.
 // WIDE: walks the four-child tree; a ray whose walk ran out of stack (Traversal::overflow) gets no hit here,
 // its slot goes to the `retry` list and wf_extend_retry traces it on the two-child tree.
+// The wide walk has no stack bound to honour (a walk that runs out is repeated on the two-child tree), so its
+// stack is sized for occupancy: 20 entries = 22 KB of LDS per workgroup = seven workgroups per CU, at 72 VGPRs
+// (seven waves per SIMD, nothing spilled).  Against six with 24 entries: -2.7 % on the million-triangle frame,
+// -5 % on the Cornell box and -4 % on the 100 k-triangle height field (the later bounces wait for memory and
+// gain most), +-0 on the glass scene, where 61 instead of 4 us per launch go into repeated walks.  Eight waves
+// (17 entries, 64 VGPRs with 15 spilled): +15 %.
+constexpr int kWideStack = 20;
+constexpr int kWideWaves = 7;
 template <bool COUNT, bool PRIMS, bool WIDE>
-__global__ __launch_bounds__(kBlock) void wf_extend(DevScene S, WfView V, const uint32_t *__restrict__ queue,
+__global__ __launch_bounds__(kBlock, WIDE ? kWideWaves : 1) void wf_extend(DevScene S, WfView V, const uint32_t *__restrict__ queue,
                                                      const uint32_t *__restrict__ qcount_in,
                                                      uint32_t *__restrict__ qcount_zero, uint32_t *__restrict__ cursors,
                                                      uint32_t *__restrict__ retry, uint32_t *__restrict__ retry_count,
                                                      int stack_limit, uint32_t hit_by_slot) {
-    __shared__ int s_stack[kStack * kBlock];
+    __shared__ int s_stack[(WIDE ? kWideStack : kStack) * kBlock];
     __shared__ uint32_t s_xchg[4][128];
     Traversal<COUNT, kExitLanes, true, WIDE> T;
-    T.limit = stack_limit;
+    T.limit = WIDE && stack_limit > kWideStack ? kWideStack : stack_limit;
     T.xchg = s_xchg[threadIdx.x >> 6];
     const uint32_t count = *qcount_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) *qcount_zero = 0u;  // the queue the next shade pass fills
@@ -673,7 +681,7 @@ __global__ void k_rng_selftest(const uint32_t *__restrict__ seeds, uint32_t nsee
 inline uint32_t pixel_grid(uint32_t W, uint32_t H) { return ((W + 15u) / 16u) * ((H + 15u) / 16u); }
 inline uint32_t ceil_blocks(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 constexpr uint32_t kPersistentBlocks = 256u * 8u;  // 256 CUs x 8 workgroups for grid-stride kernels
-constexpr uint32_t kExtendBlocks = 256u * 6u;      // 256 CUs x 6 resident workgroups (24 KB of LDS each)
+constexpr uint32_t kExtendBlocks = 256u * 6u;      // 256 CUs x 6 resident workgroups (24 KB of LDS each); the wide walk: kWideWaves
 constexpr uint32_t kRetryGrid = 64;                // the retry list is empty or nearly so
 
 }  // namespace
@@ -744,7 +752,8 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
         const uint32_t grid = (npaths + kBlock - 1) / kBlock < kPersistentBlocks ? (npaths + kBlock - 1) / kBlock
                                                                                  : kPersistentBlocks;
         // extend runs persistent waves: as many workgroups as stay resident
-        const uint32_t egrid = grid < kExtendBlocks ? grid : kExtendBlocks;
+        const uint32_t eblocks = wb.wide ? 256u * (uint32_t)kWideWaves : kExtendBlocks;
+        const uint32_t egrid = grid < eblocks ? grid : eblocks;
         timer.begin(kKernGenerate, stream);
         hipLaunchKernelGGL(wf_generate, dim3(grid), dim3(kBlock), 0, stream, S, rp, V, npaths, rp.spp_begin + done,
                            wb.qcount, wb.cursors);

@@ -99,7 +99,7 @@ struct WavefrontBuffers {
     uint32_t *binhist = nullptr;  // kWfBinWords: histogram of the cells, then their cursors
     bool sort = false;        // regroup the rays of the later bounces by cell (scenes larger than an XCD's L2)
     bool wide = true;         // wf_extend walks the four-child tree
-    int stack_limit = 24;     // entries of the traversal stack the wide walk may use (rtd::kStack; less only in tests)
+    int stack_limit = 24;     // entries of the traversal stack the wide walk may use (the kernel caps it at its own 20; less only in tests)
     uint32_t *qcount = nullptr; // [0], [1]: queue lengths (device)
     uint32_t *cursors = nullptr; // work cursors of the extend kernel, kWfCursorWords words
 };
