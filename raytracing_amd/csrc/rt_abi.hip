@@ -36,7 +36,7 @@ constexpr size_t kScratchQueue0 = kScratchHit + (size_t)kNoAllocPaths * 8;    //
 constexpr size_t kScratchQueue1 = kScratchQueue0 + (size_t)kNoAllocPaths * 4; // uint32_t[paths]
 constexpr size_t kScratchRetry = kScratchQueue1 + (size_t)kNoAllocPaths * 4; // uint32_t[2 * paths]
 constexpr size_t kScratchBin = kScratchRetry + (size_t)kNoAllocPaths * 8;     // uint16_t[paths]
-constexpr size_t kScratchQcount = kScratchBin + (size_t)kNoAllocPaths * 2;    // uint32_t[4], padded to 256 B
+constexpr size_t kScratchQcount = kScratchBin + (size_t)kNoAllocPaths * 2;    // uint32_t[kWfCountWords] = 256 B
 constexpr size_t kScratchCursors = kScratchQcount + 256;                      // uint32_t[kWfCursorWords]
 constexpr size_t kScratchBinHist = kScratchCursors + rt::kWfCursorWords * sizeof(uint32_t);  // uint32_t[kWfBinWords]
 constexpr size_t kScratchBytes = kScratchBinHist + rt::kWfBinWords * sizeof(uint32_t);
@@ -124,7 +124,7 @@ void free_wavefront(rt_scene *s) {
     dev_free(s, w.queue[1], cap);
     dev_free(s, w.bin, cap);
     dev_free(s, w.retry, cap * 2);
-    dev_free(s, w.qcount, (size_t)4);
+    dev_free(s, w.qcount, rt::kWfCountWords);
     dev_free(s, w.cursors, rt::kWfCursorWords);
     dev_free(s, w.binhist, rt::kWfBinWords);
     w = rt::WavefrontBuffers();
@@ -167,12 +167,13 @@ int ensure_wavefront(rt_scene *s, uint32_t npix, uint32_t slots) {
     RT_HIP(dev_alloc(s, &w.retry, (size_t)cap * 2));
     RT_HIP(dev_alloc(s, &w.binhist, rt::kWfBinWords));
     RT_HIP(hipMemset(w.binhist, 0, rt::kWfBinWords * sizeof(uint32_t)));
-    RT_HIP(dev_alloc(s, &w.qcount, (size_t)4));
-    RT_HIP(hipMemset(w.qcount, 0, 4 * sizeof(uint32_t)));
+    RT_HIP(dev_alloc(s, &w.qcount, rt::kWfCountWords));
+    RT_HIP(hipMemset(w.qcount, 0, rt::kWfCountWords * sizeof(uint32_t)));
     RT_HIP(dev_alloc(s, &w.cursors, rt::kWfCursorWords));
     RT_HIP(hipMemset(w.cursors, 0, rt::kWfCursorWords * sizeof(uint32_t)));
     w.capacity = cap;
     w.sort = s->sort_rays;
+    w.sort_min_pairs = s->sort_min_pairs;
     w.wide = s->wide_tree;
     w.stack_limit = s->stack_limit;
     return RT_OK;
@@ -338,11 +339,19 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
     v.tan_y = desc->camera.tan_y;
     for (int k = 0; k < 3; ++k) v.bin_scale[k] = (float)(1u << rtd::kBinBits) / (65000.f * f.grid_cell[k]);
     {
-        // Regrouping the later bounces' rays by cell (RT_WF_SORT=1) took a tenth off wf_extend while it walked
-        // the two-child tree; on the four-child tree it gains 5.6 % of wf_extend on the million-triangle scene
-        // and costs as much in sort kernels and scattered hits, and loses 7 % on the 4K glass frame: off unless asked for.
-        s->sort_rays = false;
-        if (const char *e = std::getenv("RT_WF_SORT")) s->sort_rays = std::atoi(e) != 0;
+        // Regrouping a bounce's rays by the cell they start in pays where two things hold: the tree and its
+        // triangles do not fit the L2 caches (32 MB over the eight XCDs), and the rays have lost the coherence of
+        // the pixel tiles they started in.  The first is known here; the second differs from scene to scene and
+        // bounce to bounce (after 3 bounces on the million-triangle scene, after 6 on the glass scene) and is
+        // measured by wf_shade on the device (mode 2).  RT_WF_SORT=0 / 1 / 2 forces never / every bounce /
+        // adaptive; RT_WF_SORT_MIN_PAIRS lowers the queue size below which mode 2 never sorts (tests).
+        const size_t tree_bytes = (size_t)f.nwide * 48u + (size_t)f.ntri * 64u;
+        s->sort_rays = tree_bytes >= ((size_t)32 << 20) ? 2 : 0;
+        if (const char *e = std::getenv("RT_WF_SORT")) {
+            const int m = std::atoi(e);
+            s->sort_rays = m < 0 ? 0 : (m > 2 ? 2 : m);
+        }
+        if (const char *e = std::getenv("RT_WF_SORT_MIN_PAIRS")) s->sort_min_pairs = (uint32_t)std::strtoul(e, nullptr, 10);
         // RT_WF_WIDE=0: wf_extend walks the two-child tree; RT_WF_STACK_LIMIT=n (tests): the wide walk gives up
         // beyond n stack entries, which sends rays through the retry kernel
         if (const char *e = std::getenv("RT_WF_WIDE")) s->wide_tree = std::atoi(e) != 0;
@@ -542,6 +551,7 @@ int rt_render_noalloc_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t
     wb.retry = reinterpret_cast<uint32_t *>(base + kScratchRetry);
     wb.binhist = reinterpret_cast<uint32_t *>(base + kScratchBinHist);
     wb.sort = s->sort_rays;
+    wb.sort_min_pairs = s->sort_min_pairs;
     wb.wide = s->wide_tree;
     wb.stack_limit = s->stack_limit;
     wb.qcount = reinterpret_cast<uint32_t *>(base + kScratchQcount);

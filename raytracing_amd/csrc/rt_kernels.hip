@@ -214,6 +214,8 @@ __global__ __launch_bounds__(kBlock) void k_render_replay(DevScene S, rt::Render
 // queues hold the slot indices still alive.  Slot i renders pixel frame_pixel(i % npix), sample
 // spp0 + i / npix.
 // ---------------------------------------------------------------------------------------------
+constexpr uint32_t kProbeBase = 8;        // qcount[kProbeBase + 2 b], [+ 1]: coherence probe of bounce b (b clamped to kProbeBounces - 1)
+constexpr uint32_t kProbeBounces = (rt::kWfCountWords - kProbeBase) / 2;
 constexpr uint32_t kShards = 8;           // work cursors of wf_extend (see there)
 constexpr uint32_t kCursorStride = 1024;  // words between cursors
 static_assert(kShards * kCursorStride == rt::kWfCursorWords, "cursor buffer size");
@@ -236,6 +238,25 @@ struct WfView {
     uint16_t *bin;  // [j] = ray-sorting cell of the ray at position j of the queue wf_shade is filling
     uint32_t cap;
 };
+
+// Is the queue that wf_shade has just filled traced in cell order?  mode 0: no; 1: yes; 2: if its survivors have
+// lost their coherence.  probe = {pairs of neighbouring lanes that both survived, those of them that start in the
+// same cell}, counted by that wf_shade launch over the whole queue: rays that still follow the pixel tiles share
+// cells with their neighbours (54 % of the pairs after the first bounce of the million-triangle scene, 5 %
+// after the sixth).  Measured per bounce (three launches and scattered hits against a tenth to a quarter of the
+// trace): on that scene regrouping pays from 33 % down, on the glass scene -- whose rays stay inside small
+// objects for several bounces and are cheap to trace in any order -- only from 16 % down and costs at 22 % and
+// above; the threshold is a quarter.  Every kernel that needs the answer evaluates the same two words, so no
+// flag has to travel.
+struct SortChoice {
+    uint32_t mode, min_pairs;
+    const uint32_t *probe;
+};
+__device__ __forceinline__ bool sorted_queue(const SortChoice c) {
+    if (c.mode != 2u) return c.mode == 1u;
+    const uint32_t pairs = c.probe[0], equal = c.probe[1];
+    return pairs >= c.min_pairs && equal * 4u < pairs;
+}
 
 // Record j of a frame of samples renders pixel frame_pixel(j): 8x8 pixel tiles when the image divides
 // into them, so that the 64 rays a wave works on start (and first land) close together; row order
@@ -267,6 +288,7 @@ __global__ __launch_bounds__(kBlock) void wf_generate(DevScene S, rt::RenderPara
         qcount[1] = 0u;
         qcount[2] = 0u;  // wf_extend's retry list
     }
+    if (blockIdx.x == 0 && threadIdx.x >= kProbeBase && threadIdx.x < rt::kWfCountWords) qcount[threadIdx.x] = 0u;  // wf_shade's coherence probes
     if (blockIdx.x == 0 && threadIdx.x < kShards) cursors[threadIdx.x * kCursorStride] = 0u;  // first extend pass
 }
 
@@ -298,11 +320,16 @@ constexpr int kRefill = 20;  // 4: -3 %, 12: -1 %, 16 to 24: within 0.5 %, 32: -
 constexpr int kWideStack = 20;
 constexpr int kWideWaves = 7;
 template <bool COUNT, bool PRIMS, bool WIDE>
-__global__ __launch_bounds__(kBlock, WIDE ? kWideWaves : 1) void wf_extend(DevScene S, WfView V, const uint32_t *__restrict__ queue,
+__global__ __launch_bounds__(kBlock, WIDE ? kWideWaves : 1) void wf_extend(DevScene S, WfView V, const uint32_t *__restrict__ queue_shaded,
+                                                     const uint32_t *__restrict__ queue_sorted, SortChoice choice,
                                                      const uint32_t *__restrict__ qcount_in,
                                                      uint32_t *__restrict__ qcount_zero, uint32_t *__restrict__ cursors,
                                                      uint32_t *__restrict__ retry, uint32_t *__restrict__ retry_count,
-                                                     int stack_limit, uint32_t hit_by_slot) {
+                                                     int stack_limit) {
+    // the queue in the order wf_shade filled it, or its copy regrouped by cell; hits then go to the paths' slots,
+    // because wf_shade walks the queue it filled
+    const bool hit_by_slot = queue_shaded && sorted_queue(choice);
+    const uint32_t *__restrict__ queue = hit_by_slot ? queue_sorted : queue_shaded;
     __shared__ int s_stack[(WIDE ? kWideStack : kStack) * kBlock];
     __shared__ uint32_t s_xchg[4][128];
     Traversal<COUNT, kExitLanes, true, WIDE> T;
@@ -436,7 +463,10 @@ __global__ __launch_bounds__(kBlock, TREE ? 1 : (CAMERA ? kShadeWavesCamera : kS
                                                     const uint32_t *__restrict__ qcount_in,
                                                     uint32_t *__restrict__ queue_out, uint32_t *__restrict__ qcount_out,
                                                     uint32_t *__restrict__ cursors, uint32_t depth, uint32_t want_bins,
-                                                    uint32_t *__restrict__ retry_count, uint32_t hit_by_slot) {
+                                                    uint32_t *__restrict__ retry_count, SortChoice traced,
+                                                    uint32_t *__restrict__ probe) {
+    // `traced`: how wf_extend chose the queue it traced; if a regrouped copy, the hits lie at the paths' slots
+    const bool hit_by_slot = !CAMERA && sorted_queue(traced);
     constexpr uint32_t kBuf = TREE ? kAppendBufTree : CAMERA ? kAppendBufCamera : kAppendBuf;
     const uint32_t *__restrict__ queue = CAMERA ? nullptr : queue_;  // camera rays: the identity queue
     __shared__ uint32_t s_buf[kBuf];
@@ -451,7 +481,7 @@ __global__ __launch_bounds__(kBlock, TREE ? 1 : (CAMERA ? kShadeWavesCamera : kS
     if (threadIdx.x == 0) s_count = 0u;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t lightTests = 0;
+    uint32_t lightTests = 0, probePairs = 0, probeEqual = 0;
     // every thread of the workgroup runs the same number of rounds: the barriers below are uniform
     const uint32_t stride = gridDim.x * kBlock;
     const uint32_t rounds = (count + stride - 1u) / stride;
@@ -510,6 +540,13 @@ __global__ __launch_bounds__(kBlock, TREE ? 1 : (CAMERA ? kShadeWavesCamera : kS
         // over the slots they started in, every record costing whole lines to read and masked lines to
         // write.  Runs of slots stay runs: the next bounce's waves read the queue in the order written here.
         const unsigned long long mask = __ballot(alive);
+        if (want_bins) {  // coherence probe: neighbouring lanes whose surviving paths start in the same cell
+            const uint32_t prevCell = __shfl_up(cell, 1);
+            const bool prevAlive = (mask >> ((lane + 63u) & 63u)) & 1ull;
+            const bool pair = alive && prevAlive && lane > 0u;
+            probePairs += (uint32_t)__builtin_popcountll(__ballot(pair));
+            probeEqual += (uint32_t)__builtin_popcountll(__ballot(pair && prevCell == cell));
+        }
         if (mask) {
             const int leader = __builtin_ctzll(mask);
             uint32_t base = 0;
@@ -546,6 +583,10 @@ __global__ __launch_bounds__(kBlock, TREE ? 1 : (CAMERA ? kShadeWavesCamera : kS
         }
     }
     if (lightTests) add_counters(S, 0u, TraceStats{0, 0, 0, 0}, lightTests, false);
+    if (want_bins && lane == 0u) {
+        atomicAdd(probe, probePairs);
+        atomicAdd(probe + 1, probeEqual);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -562,12 +603,14 @@ __global__ __launch_bounds__(kBlock, TREE ? 1 : (CAMERA ? kShadeWavesCamera : kS
 // entries gains a fifth of that, so it is the working set per XCD that matters, not the wave.
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kSortGrid = 1024;      // workgroups of the histogram and scatter kernels
+
 constexpr uint32_t kSortFromBounce = 1;   // the rays leaving the first hits still follow the pixel tiles: sorting them gains 1 % of wf_extend
 constexpr uint32_t kSortTile = 4 * kBins;  // entries a workgroup places at a time
 
 __global__ __launch_bounds__(kBlock) void wf_bin_hist(const uint16_t *__restrict__ bin, const uint32_t *__restrict__ qcount,
-                                                       uint32_t *__restrict__ hist) {
+                                                       uint32_t *__restrict__ hist, SortChoice choice) {
     __shared__ uint32_t s_hist[kBins];
+    if (!sorted_queue(choice)) return;
     const uint32_t count = *qcount;
     if (blockIdx.x * kBlock >= count) return;  // uniform per workgroup
     for (uint32_t b = threadIdx.x; b < kBins; b += kBlock) s_hist[b] = 0u;
@@ -581,8 +624,9 @@ __global__ __launch_bounds__(kBlock) void wf_bin_hist(const uint16_t *__restrict
 }
 
 // One workgroup: cursor[b] = number of entries in cells below b; clears the histogram for its next use.
-__global__ __launch_bounds__(kBlock) void wf_bin_scan(uint32_t *__restrict__ hist, uint32_t *__restrict__ cursor) {
+__global__ __launch_bounds__(kBlock) void wf_bin_scan(uint32_t *__restrict__ hist, uint32_t *__restrict__ cursor, SortChoice choice) {
     __shared__ uint32_t s_part[kBlock];
+    if (!sorted_queue(choice)) return;
     constexpr uint32_t per = kBins / kBlock;
     uint32_t v[per], sum = 0;
 #pragma unroll
@@ -614,8 +658,9 @@ __global__ __launch_bounds__(kBlock) void wf_bin_scan(uint32_t *__restrict__ his
 // for, the scattered 4-byte stores are.)
 __global__ __launch_bounds__(kBlock) void wf_bin_scatter(const uint32_t *__restrict__ queue_in, const uint16_t *__restrict__ bin,
                                                           const uint32_t *__restrict__ qcount, uint32_t *__restrict__ cursor,
-                                                          uint32_t *__restrict__ queue_out) {
+                                                          uint32_t *__restrict__ queue_out, SortChoice choice) {
     __shared__ uint32_t s_cell[kBins];  // entries of the tile per cell, then the next free position of the cell
+    if (!sorted_queue(choice)) return;
     const uint32_t count = *qcount;
     for (uint32_t t0 = blockIdx.x * kSortTile; t0 < count; t0 += gridDim.x * kSortTile) {  // uniform per workgroup
         const uint32_t t1 = (count - t0 < kSortTile) ? count : t0 + kSortTile;
@@ -765,20 +810,24 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
         // the buffer that is not qu (wf_extend is done with it by then); a sort then writes into qu's buffer,
         // which nothing reads any more.
         int qu = -1, qs = -1;
+        SortChoice traced{0u, wb.sort_min_pairs, wb.qcount + kProbeBase};  // how the queue of the bounce at hand was chosen
         for (uint32_t b = 0; b < bounces; ++b) {
             const uint32_t in = b & 1u, out = in ^ 1u;
-            const uint32_t *qin = (qs < 0) ? nullptr : wb.queue[qs];
+            const uint32_t *qsorted = (qs < 0) ? nullptr : wb.queue[qs];
             const uint32_t *qshade = (qu < 0) ? nullptr : wb.queue[qu];
             const int fill = (qu == 0) ? 1 : 0;
-            const bool sort = wb.sort && b >= kSortFromBounce && b + 1 < bounces;
+            // mode 2 needs a probe of its own per bounce (they are all cleared by wf_generate); paths deeper than
+            // the probes reach are not regrouped
+            const bool sort = wb.sort && b >= kSortFromBounce && b + 1 < bounces && (wb.sort == 1 || b < kProbeBounces);
+            uint32_t *probe = wb.qcount + kProbeBase + 2u * (b < kProbeBounces ? b : kProbeBounces - 1u);
             timer.begin(kKernExtend, stream);
             uint32_t *retry = wb.retry, *retryCount = wb.qcount + 2;
             auto ext = wb.wide ? (S.nprims ? (count ? wf_extend<true, true, true> : wf_extend<false, true, true>)
                                            : (count ? wf_extend<true, false, true> : wf_extend<false, false, true>))
                                : (S.nprims ? (count ? wf_extend<true, true, false> : wf_extend<false, true, false>)
                                            : (count ? wf_extend<true, false, false> : wf_extend<false, false, false>));
-            hipLaunchKernelGGL(ext, dim3(egrid), dim3(kBlock), 0, stream, S, V, qin, wb.qcount + in, wb.qcount + out, wb.cursors,
-                               retry, retryCount, wb.stack_limit, (qs != qu) ? 1u : 0u);
+            hipLaunchKernelGGL(ext, dim3(egrid), dim3(kBlock), 0, stream, S, V, qshade, qsorted, traced, wb.qcount + in,
+                               wb.qcount + out, wb.cursors, retry, retryCount, wb.stack_limit);
             if (wb.wide)
                 hipLaunchKernelGGL(count ? wf_extend_retry<true> : wf_extend_retry<false>, dim3(kRetryGrid), dim3(kBlock), 0, stream, S,
                                    V, retry, retryCount, b == 0 ? 1u : 0u);
@@ -791,16 +840,18 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
             const uint32_t sblocks = 256u * (!S.light_tree && qshade ? (uint32_t)kShadeWaves : 8u);
             hipLaunchKernelGGL(shade, dim3(grid < sblocks ? grid : sblocks), dim3(kBlock), 0, stream, S, V,
                                qshade, wb.qcount + in, wb.queue[fill], wb.qcount + out, wb.cursors,
-                               rp.max_depth - (rp.max_depth ? b : 0u), sort ? 1u : 0u, wb.qcount + 2, (qs != qu) ? 1u : 0u);
+                               rp.max_depth - (rp.max_depth ? b : 0u), sort ? 1u : 0u, wb.qcount + 2, traced, probe);
             timer.end(stream);
             qu = qs = fill;
+            traced = SortChoice{0u, wb.sort_min_pairs, probe};
             if (sort) {
+                traced.mode = (uint32_t)wb.sort;
                 const uint32_t sgrid = grid < kSortGrid ? grid : kSortGrid;
                 timer.begin(kKernSort, stream);
-                hipLaunchKernelGGL(wf_bin_hist, dim3(sgrid), dim3(kBlock), 0, stream, wb.bin, wb.qcount + out, wb.binhist);
-                hipLaunchKernelGGL(wf_bin_scan, dim3(1), dim3(kBlock), 0, stream, wb.binhist, wb.binhist + kBins);
+                hipLaunchKernelGGL(wf_bin_hist, dim3(sgrid), dim3(kBlock), 0, stream, wb.bin, wb.qcount + out, wb.binhist, traced);
+                hipLaunchKernelGGL(wf_bin_scan, dim3(1), dim3(kBlock), 0, stream, wb.binhist, wb.binhist + kBins, traced);
                 hipLaunchKernelGGL(wf_bin_scatter, dim3(sgrid), dim3(kBlock), 0, stream, wb.queue[fill], wb.bin, wb.qcount + out,
-                                   wb.binhist + kBins, wb.queue[1 - fill]);
+                                   wb.binhist + kBins, wb.queue[1 - fill], traced);
                 timer.end(stream);
                 qs = 1 - fill;
             }

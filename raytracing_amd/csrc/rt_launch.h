@@ -84,6 +84,7 @@ struct RenderParams {
 // lane and instruction, the memory system per sector), the radiance gathered so far, the hit of the bounce
 // being traced, two index queues, the retry list of the wide walk and the ray-sorting cells; plus queue
 // counters, work cursors and the cell histogram.  Owned by the scene, grown on demand.
+constexpr size_t kWfCountWords = 64;  // queue lengths [0], [1], retry count [2], coherence probes from [8] on (rt_kernels.hip)
 constexpr size_t kWfCursorWords = 8 * 1024;  // 8 cursors, 4 KB apart (rt_kernels.hip: kShards x kCursorStride)
 constexpr size_t kWfBinWords = 2 * 4096;     // histogram + cursors of the ray-sorting cells (rt_device.h: kBins)
 constexpr size_t kWfBytesPerPath = 16 + 16 + 16 + 16 + 8 + 4 + 4 + 8 + 2;
@@ -97,10 +98,12 @@ struct WavefrontBuffers {
     uint32_t *retry = nullptr;  // 2 x capacity: (slot, hit position) of the rays whose walk of the four-child tree ran out of stack
     uint16_t *bin = nullptr;  // capacity: ray-sorting cell of each entry of the queue being filled
     uint32_t *binhist = nullptr;  // kWfBinWords: histogram of the cells, then their cursors
-    bool sort = false;        // regroup the rays of the later bounces by cell (scenes larger than an XCD's L2)
+    int sort = 0;             // regroup the rays of the later bounces by cell: 0 never, 1 every bounce, 2 where a bounce's
+                              // survivors have lost their coherence (decided on the device, see wf_shade)
+    uint32_t sort_min_pairs = 1u << 20;  // mode 2: queues with fewer neighbouring survivors are not worth three launches
     bool wide = true;         // wf_extend walks the four-child tree
     int stack_limit = 24;     // entries of the traversal stack the wide walk may use (the kernel caps it at its own 20; less only in tests)
-    uint32_t *qcount = nullptr; // [0], [1]: queue lengths (device)
+    uint32_t *qcount = nullptr; // kWfCountWords words: queue lengths, retry count, coherence probes (device)
     uint32_t *cursors = nullptr; // work cursors of the extend kernel, kWfCursorWords words
 };
 

@@ -308,15 +308,17 @@ def test_wavefront_multi_pass_matches_single_pass_and_oracle(scene_dir, oracle_m
     ("glass", {"grid": 3, "subdiv": 2}, 96, 72, 16),
 ])
 def test_wavefront_ray_sorting_changes_no_result(scene_dir, oracle_mod, monkeypatch, name, kw, W, H, depth):
-    """From the second bounce on the wavefront pipeline regroups the ray queue by the cell of the ray origin
-    (on by itself only for scenes larger than an XCD's L2; RT_WF_SORT forces it).  Only the order in which
-    rays are traced changes: every path's arithmetic is its own and sums are taken per slot, so the sorted
-    render is bit-equal to the unsorted one, with equal segment and light-test counts, one pass or several."""
+    """From the second bounce on the wavefront pipeline can regroup the ray queue by the cell of the ray origin:
+    RT_WF_SORT=1 on every bounce, =2 on the bounces whose survivors have lost their coherence (decided on the
+    device from a probe the shading kernel counts; the default for scenes larger than the L2 caches), =0 never.
+    Only the order in which rays are traced changes: every path's arithmetic is its own and sums are taken per
+    slot, so all three renders are bit-equal, with equal segment and light-test counts, one pass or several."""
     import raytracing_amd as rt
     host, _, orc = _load(scene_dir, oracle_mod, name, W, H, **kw)
     ref, c_o = orc.render(W, H, 6, max_depth=depth, rng_mode=1, seed=21, spp_begin=2)
     outs = {}
-    for flag in ("0", "1"):
+    monkeypatch.setenv("RT_WF_SORT_MIN_PAIRS", "0")              # the adaptive mode ignores small queues otherwise
+    for flag in ("0", "1", "2"):
         monkeypatch.setenv("RT_WF_SORT", flag)
         monkeypatch.delenv("RT_WF_PATHS", raising=False)
         with rt.Scene(host, device=0) as gpu:
@@ -326,12 +328,15 @@ def test_wavefront_ray_sorting_changes_no_result(scene_dir, oracle_mod, monkeypa
             c = gpu.counters()
             assert c["segments"] == c_o["segments"] and c["light_tests"] == c_o["light_tests"]
             sorts = gpu.kernel_times()["sort"][1]
-            assert sorts == (depth - 2 if flag == "1" else 0)   # bounces 1 .. depth-2 hand a sorted queue on
+            assert sorts == (0 if flag == "0" else depth - 2)   # bounces 1 .. depth-2 can hand a sorted queue on
         _assert_close(outs[flag], ref)
     _assert_bits_equal(outs["1"], outs["0"])
+    _assert_bits_equal(outs["2"], outs["0"])
     monkeypatch.setenv("RT_WF_PATHS", str(2 * W * H))           # three passes of two frames
-    with rt.Scene(host, device=0) as gpu:
-        _assert_bits_equal(gpu.render(W, H, 6, max_depth=depth, rng_mode=1, seed=21, spp_begin=2, pipeline=rt.PIPE_WAVEFRONT), outs["0"])
+    for flag in ("1", "2"):
+        monkeypatch.setenv("RT_WF_SORT", flag)
+        with rt.Scene(host, device=0) as gpu:
+            _assert_bits_equal(gpu.render(W, H, 6, max_depth=depth, rng_mode=1, seed=21, spp_begin=2, pipeline=rt.PIPE_WAVEFRONT), outs["0"])
 
 
 @pytest.mark.parametrize("name,kw,W,H,depth", [

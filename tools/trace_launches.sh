@@ -15,7 +15,7 @@ rows = []
 for f in glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        for s in ("wf_extend", "wf_shade", "wf_generate", "wf_accumulate"):
+        for s in ("wf_extend", "wf_shade", "wf_generate", "wf_accumulate", "wf_bin_scatter", "wf_bin_hist"):
             if s in n and "retry" not in n:
                 rows.append((int(r["Start_Timestamp"]), s, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6))
 rows.sort()
@@ -23,7 +23,11 @@ rows.sort()
 last = max(i for i, r in enumerate(rows) if r[1] == "wf_generate")
 ext = [r[2] for r in rows[last:] if r[1] == "wf_extend"]
 shd = [r[2] for r in rows[last:] if r[1] == "wf_shade"]
+srt = [r[2] for r in rows[last:] if r[1] == "wf_bin_scatter"]
+hst = [r[2] for r in rows[last:] if r[1] == "wf_bin_hist"]
 for b, (e, s) in enumerate(zip(ext, shd)):
     print("bounce %d extend %.3f ms shade %.3f ms" % (b, e, s))
+if srt:
+    print("sort launches (histogram + scatter, ms):", " ".join("%.3f" % (a + c) for a, c in zip(hst, srt)))
 print("sum extend %.3f shade %.3f" % (sum(ext), sum(shd)))
 PY
