@@ -9,7 +9,7 @@
 //                    the same estimator as queue-per-bounce kernels over 48-byte path records; wf_extend
 //                    walks the four-child tree, everything else the two-child one
 //   wf_bin_hist / wf_bin_scan / wf_bin_scatter
-//                    optional regrouping of a ray queue by the cell of the ray origin (RT_WF_SORT=1)
+//                    regrouping of a ray queue by the cell of the ray origin where its paths have lost their coherence (RT_WF_SORT)
 //   k_tonemap        mean, ACES, gamma, byte conversion               (main.cpp:1226-1231, 840-846)
 //
 // Pixel kernels map a wave to an 8x8 pixel tile (coherent primary rays) and a workgroup to a
@@ -590,21 +590,22 @@ __global__ __launch_bounds__(kBlock, TREE ? 1 : (CAMERA ? kShadeWavesCamera : kS
 }
 
 // ---------------------------------------------------------------------------------------------
-// Ray sorting.  From the second bounce on the survivors of a pass are scattered over the whole scene, and
-// rays that are traced at the same time touch unrelated parts of a tree that is far larger than an XCD's
-// L2: the same 47 node visits per ray that cost 0.16 ns at the first bounce cost 0.4 ns at the last.  The
-// queue is therefore regrouped by the cell of the ray origin (ray_bin: 4096 cells in Morton order) before
-// it is traced -- a counting sort in three small kernels, entirely on the device (the queue length never
-// visits the host): histogram of the cells wf_shade wrote next to the queue, exclusive scan, scatter.
-// Only path INDICES move; records stay in their slots.  The order inside a cell is whatever the atomics
-// make it, which no result depends on: every path's arithmetic is its own and sums are taken per slot.
+// Ray sorting.  After a few bounces the survivors of a pass are scattered over the whole scene, and rays
+// that are traced at the same time touch unrelated parts of a tree that is far larger than an XCD's L2:
+// the same node visits per ray cost 2.3 times as much at the last bounce as at the second.  A queue whose
+// paths have lost their coherence (SortChoice) is therefore regrouped by the cell of the ray origin
+// (ray_bin: 4096 cells in Morton order) before it is traced -- a counting sort in three small kernels,
+// entirely on the device (the queue length never visits the host): histogram of the cells wf_shade wrote
+// next to the queue, exclusive scan, scatter.  Only path INDICES move here.  The order inside a cell is
+// whatever the atomics make it, which no result depends on: every path's arithmetic is its own and sums
+// are taken per home slot.
 // Measured on the million-triangle frame (64 samples per pass): wf_extend 70.2 -> 55.2 ms with 4096
 // cells (512: 57.1, 64: 60.6, 8: 65.9; 2^24 cells: 52.7); sorting only inside blocks of 2K to 128K
 // entries gains a fifth of that, so it is the working set per XCD that matters, not the wave.
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kSortGrid = 1024;      // workgroups of the histogram and scatter kernels
 
-constexpr uint32_t kSortFromBounce = 1;   // the rays leaving the first hits still follow the pixel tiles: sorting them gains 1 % of wf_extend
+constexpr uint32_t kSortFromBounce = 1;   // the rays leaving the first hits still follow the pixel tiles: never sorted
 constexpr uint32_t kSortTile = 4 * kBins;  // entries a workgroup places at a time
 
 __global__ __launch_bounds__(kBlock) void wf_bin_hist(const uint16_t *__restrict__ bin, const uint32_t *__restrict__ qcount,
