@@ -126,7 +126,7 @@ struct DevScene {
     unsigned long long *counters;  // kCounterShards x kCounterStride; per shard [0] segments [1] nodes [2] tri tests [3] light tests
     uint32_t nlights, nmats;
     uint32_t ntri, nprims;               // a hit index >= ntri names analytic primitive (index - ntri)
-    uint32_t light_tree;                 // nonzero: the launchers pick the kernels whose light_pdf walks lnodes
+    uint32_t light_tree;                 // nonzero: the launchers pick the kernels whose light_pdf walks lnodes; the value is that tree's height
     float grid_origin[3], grid_cell[3];  // node-box plane = origin + q * cell, q a 16-bit integer
     float lgrid_origin[3], lgrid_cell[3];  // the same for lnodes
     float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];

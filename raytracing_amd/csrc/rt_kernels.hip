@@ -458,8 +458,12 @@ constexpr int kShadeWaves = 6;
 // The instantiation for the camera rays (CAMERA: no queue, 16-byte records, the home slot is the slot) needs
 // fewer registers and runs at eight waves with two spills: 5.5 instead of 6.0 ms for the first launch of that pass.
 constexpr int kShadeWavesCamera = 8;
-template <bool TREE, bool CAMERA>
-__global__ __launch_bounds__(kBlock, TREE ? 1 : (CAMERA ? kShadeWavesCamera : kShadeWaves)) void wf_shade(DevScene S, WfView V, const uint32_t *__restrict__ queue_,
+// The light-tree instantiations hold a traversal stack in LDS: LSTACK entries, 24 in general and 16 for light
+// trees of at most 16 levels (the walk pushes at most one reference per level), which lets five instead of four
+// workgroups share a CU (96 VGPRs): -3.7 % on the 15 360-light frame.
+constexpr int kLightStackShort = 16;
+template <bool TREE, bool CAMERA, int LSTACK = kStack>
+__global__ __launch_bounds__(kBlock, TREE ? (LSTACK == kLightStackShort ? 5 : 1) : (CAMERA ? kShadeWavesCamera : kShadeWaves)) void wf_shade(DevScene S, WfView V, const uint32_t *__restrict__ queue_,
                                                     const uint32_t *__restrict__ qcount_in,
                                                     uint32_t *__restrict__ queue_out, uint32_t *__restrict__ qcount_out,
                                                     uint32_t *__restrict__ cursors, uint32_t depth, uint32_t want_bins,
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(kBlock, TREE ? 1 : (CAMERA ? kShadeWavesCamera : kS
     __shared__ uint16_t s_bin[kBuf];
     __shared__ uint32_t s_count, s_base;
     __shared__ LightCacheStorage s_lights;
-    __shared__ int s_stack[TREE ? kStack * kBlock : 1];  // light_pdf's walk of the light tree
+    __shared__ int s_stack[TREE ? LSTACK * kBlock : 1];  // light_pdf's walk of the light tree
     const LightCache LC = load_light_cache(S, s_lights, s_stack + (TREE ? threadIdx.x : 0));
     const uint32_t count = *qcount_in;
     if (blockIdx.x == 0 && threadIdx.x < kShards) cursors[threadIdx.x * kCursorStride] = 0u;  // next extend pass
@@ -834,8 +838,10 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
                                    V, retry, retryCount, b == 0 ? 1u : 0u);
             timer.end(stream);
             timer.begin(kKernShade, stream);
-            auto shade = S.light_tree ? (qshade ? wf_shade<true, false> : wf_shade<true, true>)
-                                      : (qshade ? wf_shade<false, false> : wf_shade<false, true>);
+            auto shade = !S.light_tree ? (qshade ? wf_shade<false, false> : wf_shade<false, true>)
+                         : S.light_tree <= (uint32_t)kLightStackShort
+                             ? (qshade ? wf_shade<true, false, kLightStackShort> : wf_shade<true, true, kLightStackShort>)
+                             : (qshade ? wf_shade<true, false> : wf_shade<true, true>);
             // as many workgroups as stay resident (2048 at six per CU ran the last quarter of them after the rest:
             // 25.4 instead of 24.7 ms per pass); the light-tree variant balances better with more, smaller shares
             const uint32_t sblocks = 256u * (!S.light_tree && qshade ? (uint32_t)kShadeWaves : 8u);

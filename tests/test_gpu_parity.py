@@ -686,6 +686,10 @@ def test_light_tree_matches_the_loop_over_all_lights(scene_dir, oracle_mod, monk
         assert c["segments"] == c_c["segments"]
         if name == "emissive":   # the point of the tree: far fewer exact light tests than lights x vertices
             assert c["light_tests"] < 0.05 * c_c["light_tests"]
+    # the wavefront shading kernel keeps a 16-entry stack for shallow light trees and a 24-entry one otherwise
+    monkeypatch.setenv("RT_LIGHT_STACK_FULL", "1")
+    with rt.Scene(host, device=0) as gpu2:
+        _assert_bits_equal(gpu2.render(W, H, spp, max_depth=depth, rng_mode=rt.RNG_COUNTER, seed=3, pipeline=rt.PIPE_WAVEFRONT), out_c)
 
 
 @pytest.mark.parametrize("seed,n_emissive", [(5, 6), (6, 200)])
