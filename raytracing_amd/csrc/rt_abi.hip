@@ -39,7 +39,8 @@ constexpr size_t kScratchBin = kScratchRetry + (size_t)kNoAllocPaths * 8;     //
 constexpr size_t kScratchQcount = kScratchBin + (size_t)kNoAllocPaths * 2;    // uint32_t[kWfCountWords] = 256 B
 constexpr size_t kScratchCursors = kScratchQcount + 256;                      // uint32_t[kWfCursorWords]
 constexpr size_t kScratchBinHist = kScratchCursors + rt::kWfCursorWords * sizeof(uint32_t);  // uint32_t[kWfBinWords]
-constexpr size_t kScratchBytes = kScratchBinHist + rt::kWfBinWords * sizeof(uint32_t);
+constexpr size_t kScratchTuner = kScratchBinHist + rt::kWfBinWords * sizeof(uint32_t);             // uint32_t[kWfTuneWords]
+constexpr size_t kScratchBytes = kScratchTuner + rt::kWfTuneWords * sizeof(uint32_t);
 }  // namespace
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 
@@ -126,6 +127,7 @@ void free_wavefront(rt_scene *s) {
     dev_free(s, w.retry, cap * 2);
     dev_free(s, w.qcount, rt::kWfCountWords);
     dev_free(s, w.cursors, rt::kWfCursorWords);
+    dev_free(s, w.tuner, rt::kWfTuneWords);
     dev_free(s, w.binhist, rt::kWfBinWords);
     w = rt::WavefrontBuffers();
 }
@@ -171,9 +173,11 @@ int ensure_wavefront(rt_scene *s, uint32_t npix, uint32_t slots) {
     RT_HIP(hipMemset(w.qcount, 0, rt::kWfCountWords * sizeof(uint32_t)));
     RT_HIP(dev_alloc(s, &w.cursors, rt::kWfCursorWords));
     RT_HIP(hipMemset(w.cursors, 0, rt::kWfCursorWords * sizeof(uint32_t)));
+    RT_HIP(dev_alloc(s, &w.tuner, rt::kWfTuneWords));
+    RT_HIP(hipMemset(w.tuner, 0, rt::kWfTuneWords * sizeof(uint32_t)));
     w.capacity = cap;
     w.sort = s->sort_rays;
-    w.sort_min_pairs = s->sort_min_pairs;
+    w.sort_min_rays = s->sort_min_rays;
     w.wide = s->wide_tree;
     w.stack_limit = s->stack_limit;
     return RT_OK;
@@ -345,16 +349,17 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
         // Regrouping a bounce's rays by the cell they start in pays where two things hold: the tree and its
         // triangles do not fit the L2 caches (32 MB over the eight XCDs), and the rays have lost the coherence of
         // the pixel tiles they started in.  The first is known here; the second differs from scene to scene and
-        // bounce to bounce (after 3 bounces on the million-triangle scene, after 6 on the glass scene) and is
-        // measured by wf_shade on the device (mode 2).  RT_WF_SORT=0 / 1 / 2 forces never / every bounce /
-        // adaptive; RT_WF_SORT_MIN_PAIRS lowers the queue size below which mode 2 never sorts (tests).
+        // bounce to bounce (from the fourth bounce on the million-triangle scene, from the seventh on the glass
+        // scene) and is found out by measuring on the device (mode 2: the tuner of rt_kernels.hip).
+        // RT_WF_SORT=0 / 1 / 2 forces never / every bounce / tuned; RT_WF_SORT_MIN_RAYS lowers the queue length
+        // below which mode 2 never sorts (tests).
         const size_t tree_bytes = (size_t)f.nwide * 48u + (size_t)f.ntri * 64u;
         s->sort_rays = tree_bytes >= ((size_t)32 << 20) ? 2 : 0;
         if (const char *e = std::getenv("RT_WF_SORT")) {
             const int m = std::atoi(e);
             s->sort_rays = m < 0 ? 0 : (m > 2 ? 2 : m);
         }
-        if (const char *e = std::getenv("RT_WF_SORT_MIN_PAIRS")) s->sort_min_pairs = (uint32_t)std::strtoul(e, nullptr, 10);
+        if (const char *e = std::getenv("RT_WF_SORT_MIN_RAYS")) s->sort_min_rays = (uint32_t)std::strtoul(e, nullptr, 10);
         // RT_WF_WIDE=0: wf_extend walks the two-child tree; RT_WF_STACK_LIMIT=n (tests): the wide walk gives up
         // beyond n stack entries, which sends rays through the retry kernel
         if (const char *e = std::getenv("RT_WF_WIDE")) s->wide_tree = std::atoi(e) != 0;
@@ -554,11 +559,12 @@ int rt_render_noalloc_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t
     wb.retry = reinterpret_cast<uint32_t *>(base + kScratchRetry);
     wb.binhist = reinterpret_cast<uint32_t *>(base + kScratchBinHist);
     wb.sort = s->sort_rays;
-    wb.sort_min_pairs = s->sort_min_pairs;
+    wb.sort_min_rays = s->sort_min_rays;
     wb.wide = s->wide_tree;
     wb.stack_limit = s->stack_limit;
     wb.qcount = reinterpret_cast<uint32_t *>(base + kScratchQcount);
     wb.cursors = reinterpret_cast<uint32_t *>(base + kScratchCursors);
+    wb.tuner = reinterpret_cast<uint32_t *>(base + kScratchTuner);
     // the array keeps the previous call's contents: counters and cursors start from zero, the records
     // and queues are rewritten by wf_generate / wf_shade before they are read
     RT_HIP(hipMemsetAsync(base + kScratchQcount, 0, kScratchBytes - kScratchQcount, (hipStream_t)stream));

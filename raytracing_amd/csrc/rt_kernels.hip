@@ -214,8 +214,6 @@ __global__ __launch_bounds__(kBlock) void k_render_replay(DevScene S, rt::Render
 // queues hold the slot indices still alive.  Slot i renders pixel frame_pixel(i % npix), sample
 // spp0 + i / npix.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kProbeBase = 8;        // qcount[kProbeBase + 2 b], [+ 1]: coherence probe of bounce b (b clamped to kProbeBounces - 1)
-constexpr uint32_t kProbeBounces = (rt::kWfCountWords - kProbeBase) / 2;
 constexpr uint32_t kShards = 8;           // work cursors of wf_extend (see there)
 constexpr uint32_t kCursorStride = 1024;  // words between cursors
 static_assert(kShards * kCursorStride == rt::kWfCursorWords, "cursor buffer size");
@@ -239,23 +237,42 @@ struct WfView {
     uint32_t cap;
 };
 
-// Is the queue that wf_shade has just filled traced in cell order?  mode 0: no; 1: yes; 2: if its survivors have
-// lost their coherence.  probe = {pairs of neighbouring lanes that both survived, those of them that start in the
-// same cell}, counted by that wf_shade launch over the whole queue: rays that still follow the pixel tiles share
-// cells with their neighbours (54 % of the pairs after the first bounce of the million-triangle scene, 5 %
-// after the sixth).  Measured per bounce (three launches and scattered hits against a tenth to a quarter of the
-// trace): on that scene regrouping pays from 33 % down, on the glass scene -- whose rays stay inside small
-// objects for several bounces and are cheap to trace in any order -- only from 16 % down and costs at 22 % and
-// above; the threshold is a quarter.  Every kernel that needs the answer evaluates the same two words, so no
-// flag has to travel.
+// Is the queue of a bounce traced in cell order?  mode 0: no; 1: yes; 2: as the tuner decided (*decision).
+//
+// The tuner (mode 2).  Whether regrouping a bounce's rays pays differs from scene to scene and from bounce to
+// bounce -- on the million-triangle scene from the fourth bounce on (a third of neighbouring lanes still start
+// in the same cell there), on the glass scene only from the seventh (a sixth), and measures of the rays'
+// coherence do not tell the two apart: what differs is what incoherence costs.  So the cost itself is
+// measured.  Every pass of a frame traces statistically the same rays, bounce by bounce; the last workgroup
+// of every wf_shade launch leaves the time, the last workgroup of the next wf_extend launch takes the
+// difference -- the sort launches, if any, and the trace -- per ray, files it under "sorted" or "unsorted" of
+// its bounce (a running mean) and decides the next bounce: unsorted until that has been measured, then sorted
+// until that has, then whichever was cheaper, with the other one tried again every 64th decision.  Everything
+// lives in `tune` (device memory of the scene, kept from pass to pass and call to call); nothing returns to
+// the host, and the kernels that need a decision (wf_shade for the cells, the sort kernels, wf_extend,
+// the next wf_shade for where the hits lie) read the same word.
+//   tune[0..1] time mark   [2] finished workgroups of the launch at hand   [3] decisions taken
+//   tune[8 + 4 b ..]: bounce b: cost unsorted, cost sorted (2^-20 ticks of 10 ns per ray), decision, unused
+constexpr uint32_t kTuneBounces = (rt::kWfTuneWords - 8u) / 4u;
 struct SortChoice {
-    uint32_t mode, min_pairs;
-    const uint32_t *probe;
+    uint32_t mode;
+    const uint32_t *decision;
 };
 __device__ __forceinline__ bool sorted_queue(const SortChoice c) {
-    if (c.mode != 2u) return c.mode == 1u;
-    const uint32_t pairs = c.probe[0], equal = c.probe[1];
-    return pairs >= c.min_pairs && equal * 4u < pairs;
+    return c.mode == 1u || (c.mode == 2u && *c.decision != 0u);
+}
+__device__ __forceinline__ uint32_t *tune_bounce(uint32_t *tune, uint32_t b) {
+    return tune + 8u + 4u * (b < kTuneBounces ? b : kTuneBounces - 1u);
+}
+// True in exactly one thread of the launch: thread 0 of the workgroup that finishes last.  Every thread of
+// every workgroup must call it.
+__device__ __forceinline__ bool last_workgroup(uint32_t *tune) {
+    __syncthreads();
+    if (threadIdx.x != 0u) return false;
+    __threadfence();
+    if (atomicAdd(tune + 2, 1u) != gridDim.x - 1u) return false;
+    tune[2] = 0u;
+    return true;
 }
 
 // Record j of a frame of samples renders pixel frame_pixel(j): 8x8 pixel tiles when the image divides
@@ -288,7 +305,6 @@ __global__ __launch_bounds__(kBlock) void wf_generate(DevScene S, rt::RenderPara
         qcount[1] = 0u;
         qcount[2] = 0u;  // wf_extend's retry list
     }
-    if (blockIdx.x == 0 && threadIdx.x >= kProbeBase && threadIdx.x < rt::kWfCountWords) qcount[threadIdx.x] = 0u;  // wf_shade's coherence probes
     if (blockIdx.x == 0 && threadIdx.x < kShards) cursors[threadIdx.x * kCursorStride] = 0u;  // first extend pass
 }
 
@@ -325,7 +341,8 @@ __global__ __launch_bounds__(kBlock, WIDE ? kWideWaves : 1) void wf_extend(DevSc
                                                      const uint32_t *__restrict__ qcount_in,
                                                      uint32_t *__restrict__ qcount_zero, uint32_t *__restrict__ cursors,
                                                      uint32_t *__restrict__ retry, uint32_t *__restrict__ retry_count,
-                                                     int stack_limit) {
+                                                     int stack_limit, uint32_t *__restrict__ tune, uint32_t bounce,
+                                                     uint32_t sort_min_rays) {
     // the queue in the order wf_shade filled it, or its copy regrouped by cell; hits then go to the paths' slots,
     // because wf_shade walks the queue it filled
     const bool hit_by_slot = queue_shaded && sorted_queue(choice);
@@ -407,6 +424,26 @@ __global__ __launch_bounds__(kBlock, WIDE ? kWideWaves : 1) void wf_extend(DevSc
         T.step(S, st);
     }
     if (segs) add_counters(S, segs, st, 0u, COUNT);
+    if (tune && last_workgroup(tune)) {  // the tuner: file this bounce's cost, decide the next bounce
+        const unsigned long long now = wall_clock64(), mark = *reinterpret_cast<const unsigned long long *>(tune);
+        if (bounce >= 2u && bounce < kTuneBounces && count) {
+            uint32_t *cost = tune_bounce(tune, bounce) + (hit_by_slot ? 1 : 0);
+            const unsigned long long m = ((now - mark) << 20) / count;
+            const uint32_t v = m > 0xFFFFFFFFull ? 0xFFFFFFFFu : (m ? (uint32_t)m : 1u), old = *cost;
+            *cost = old ? (uint32_t)((3ull * old + v) >> 2) : v;
+        }
+        const uint32_t next = bounce + 1u;
+        uint32_t d = 0u;
+        if (next >= 2u && next < kTuneBounces && count >= sort_min_rays) {
+            const uint32_t *t = tune_bounce(tune, next);
+            if (t[0] && !t[1]) d = 1u;
+            else if (t[0] && t[1]) {
+                d = t[1] < t[0] ? 1u : 0u;
+                if ((tune[3]++ & 63u) == 63u) d ^= 1u;
+            }
+        }
+        tune_bounce(tune, next)[2] = d;
+    }
 }
 
 // The rays wf_extend<WIDE> gave up on, one lane each, on the two-child tree (whose height bounds the stack).
@@ -466,11 +503,13 @@ template <bool TREE, bool CAMERA, int LSTACK = kStack>
 __global__ __launch_bounds__(kBlock, TREE ? (LSTACK == kLightStackShort ? 5 : 1) : (CAMERA ? kShadeWavesCamera : kShadeWaves)) void wf_shade(DevScene S, WfView V, const uint32_t *__restrict__ queue_,
                                                     const uint32_t *__restrict__ qcount_in,
                                                     uint32_t *__restrict__ queue_out, uint32_t *__restrict__ qcount_out,
-                                                    uint32_t *__restrict__ cursors, uint32_t depth, uint32_t want_bins,
+                                                    uint32_t *__restrict__ cursors, uint32_t depth, SortChoice next,
                                                     uint32_t *__restrict__ retry_count, SortChoice traced,
-                                                    uint32_t *__restrict__ probe) {
-    // `traced`: how wf_extend chose the queue it traced; if a regrouped copy, the hits lie at the paths' slots
+                                                    uint32_t *__restrict__ tune) {
+    // `traced`: how wf_extend chose the queue it traced; if a regrouped copy, the hits lie at the paths' slots.
+    // `next`: whether the queue filled here will be regrouped, i.e. whether its cells are wanted.
     const bool hit_by_slot = !CAMERA && sorted_queue(traced);
+    const bool want_bins = sorted_queue(next);
     constexpr uint32_t kBuf = TREE ? kAppendBufTree : CAMERA ? kAppendBufCamera : kAppendBuf;
     const uint32_t *__restrict__ queue = CAMERA ? nullptr : queue_;  // camera rays: the identity queue
     __shared__ uint32_t s_buf[kBuf];
@@ -485,7 +524,7 @@ __global__ __launch_bounds__(kBlock, TREE ? (LSTACK == kLightStackShort ? 5 : 1)
     if (threadIdx.x == 0) s_count = 0u;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t lightTests = 0, probePairs = 0, probeEqual = 0;
+    uint32_t lightTests = 0;
     // every thread of the workgroup runs the same number of rounds: the barriers below are uniform
     const uint32_t stride = gridDim.x * kBlock;
     const uint32_t rounds = (count + stride - 1u) / stride;
@@ -544,13 +583,6 @@ __global__ __launch_bounds__(kBlock, TREE ? (LSTACK == kLightStackShort ? 5 : 1)
         // over the slots they started in, every record costing whole lines to read and masked lines to
         // write.  Runs of slots stay runs: the next bounce's waves read the queue in the order written here.
         const unsigned long long mask = __ballot(alive);
-        if (want_bins) {  // coherence probe: neighbouring lanes whose surviving paths start in the same cell
-            const uint32_t prevCell = __shfl_up(cell, 1);
-            const bool prevAlive = (mask >> ((lane + 63u) & 63u)) & 1ull;
-            const bool pair = alive && prevAlive && lane > 0u;
-            probePairs += (uint32_t)__builtin_popcountll(__ballot(pair));
-            probeEqual += (uint32_t)__builtin_popcountll(__ballot(pair && prevCell == cell));
-        }
         if (mask) {
             const int leader = __builtin_ctzll(mask);
             uint32_t base = 0;
@@ -587,10 +619,7 @@ __global__ __launch_bounds__(kBlock, TREE ? (LSTACK == kLightStackShort ? 5 : 1)
         }
     }
     if (lightTests) add_counters(S, 0u, TraceStats{0, 0, 0, 0}, lightTests, false);
-    if (want_bins && lane == 0u) {
-        atomicAdd(probe, probePairs);
-        atomicAdd(probe + 1, probeEqual);
-    }
+    if (tune && last_workgroup(tune)) *reinterpret_cast<unsigned long long *>(tune) = wall_clock64();  // the tuner's time mark
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -738,6 +767,8 @@ constexpr uint32_t kRetryGrid = 64;                // the retry list is empty or
 
 namespace rt {
 
+static uint32_t *tune_bounce_host(uint32_t *tune, uint32_t b) { return tune + 8u + 4u * (b < kTuneBounces ? b : kTuneBounces - 1u); }
+
 hipError_t launch_intersect(const DevScene &S, uint64_t n, const float *o, const float *d, uint32_t *prim_id, float *t,
                             bool count, hipStream_t stream, KernelTimer &timer) {
     if (n == 0) return hipSuccess;
@@ -815,16 +846,16 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
         // the buffer that is not qu (wf_extend is done with it by then); a sort then writes into qu's buffer,
         // which nothing reads any more.
         int qu = -1, qs = -1;
-        SortChoice traced{0u, wb.sort_min_pairs, wb.qcount + kProbeBase};  // how the queue of the bounce at hand was chosen
+        uint32_t *tune = wb.sort == 2 ? wb.tuner : nullptr;
+        SortChoice traced{0u, wb.tuner + 10};  // how the queue of the bounce at hand was chosen
         for (uint32_t b = 0; b < bounces; ++b) {
             const uint32_t in = b & 1u, out = in ^ 1u;
             const uint32_t *qsorted = (qs < 0) ? nullptr : wb.queue[qs];
             const uint32_t *qshade = (qu < 0) ? nullptr : wb.queue[qu];
             const int fill = (qu == 0) ? 1 : 0;
-            // mode 2 needs a probe of its own per bounce (they are all cleared by wf_generate); paths deeper than
-            // the probes reach are not regrouped
-            const bool sort = wb.sort && b >= kSortFromBounce && b + 1 < bounces && (wb.sort == 1 || b < kProbeBounces);
-            uint32_t *probe = wb.qcount + kProbeBase + 2u * (b < kProbeBounces ? b : kProbeBounces - 1u);
+            // may the queue this bounce fills be regrouped?  (the tuner keeps books for kTuneBounces bounces)
+            const bool sort = wb.sort && b >= kSortFromBounce && b + 1 < bounces && (wb.sort == 1 || b + 1 < kTuneBounces);
+            const SortChoice next{sort ? (uint32_t)wb.sort : 0u, tune_bounce_host(wb.tuner, b + 1) + 2};
             timer.begin(kKernExtend, stream);
             uint32_t *retry = wb.retry, *retryCount = wb.qcount + 2;
             auto ext = wb.wide ? (S.nprims ? (count ? wf_extend<true, true, true> : wf_extend<false, true, true>)
@@ -832,7 +863,7 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
                                : (S.nprims ? (count ? wf_extend<true, true, false> : wf_extend<false, true, false>)
                                            : (count ? wf_extend<true, false, false> : wf_extend<false, false, false>));
             hipLaunchKernelGGL(ext, dim3(egrid), dim3(kBlock), 0, stream, S, V, qshade, qsorted, traced, wb.qcount + in,
-                               wb.qcount + out, wb.cursors, retry, retryCount, wb.stack_limit);
+                               wb.qcount + out, wb.cursors, retry, retryCount, wb.stack_limit, tune, b, wb.sort_min_rays);
             if (wb.wide)
                 hipLaunchKernelGGL(count ? wf_extend_retry<true> : wf_extend_retry<false>, dim3(kRetryGrid), dim3(kBlock), 0, stream, S,
                                    V, retry, retryCount, b == 0 ? 1u : 0u);
@@ -847,12 +878,11 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
             const uint32_t sblocks = 256u * (!S.light_tree && qshade ? (uint32_t)kShadeWaves : 8u);
             hipLaunchKernelGGL(shade, dim3(grid < sblocks ? grid : sblocks), dim3(kBlock), 0, stream, S, V,
                                qshade, wb.qcount + in, wb.queue[fill], wb.qcount + out, wb.cursors,
-                               rp.max_depth - (rp.max_depth ? b : 0u), sort ? 1u : 0u, wb.qcount + 2, traced, probe);
+                               rp.max_depth - (rp.max_depth ? b : 0u), next, wb.qcount + 2, traced, tune);
             timer.end(stream);
             qu = qs = fill;
-            traced = SortChoice{0u, wb.sort_min_pairs, probe};
+            traced = next;
             if (sort) {
-                traced.mode = (uint32_t)wb.sort;
                 const uint32_t sgrid = grid < kSortGrid ? grid : kSortGrid;
                 timer.begin(kKernSort, stream);
                 hipLaunchKernelGGL(wf_bin_hist, dim3(sgrid), dim3(kBlock), 0, stream, wb.bin, wb.qcount + out, wb.binhist, traced);

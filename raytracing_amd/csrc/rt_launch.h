@@ -84,7 +84,8 @@ struct RenderParams {
 // lane and instruction, the memory system per sector), the radiance gathered so far, the hit of the bounce
 // being traced, two index queues, the retry list of the wide walk and the ray-sorting cells; plus queue
 // counters, work cursors and the cell histogram.  Owned by the scene, grown on demand.
-constexpr size_t kWfCountWords = 64;  // queue lengths [0], [1], retry count [2], coherence probes from [8] on (rt_kernels.hip)
+constexpr size_t kWfCountWords = 64;  // queue lengths [0], [1], retry count [2]
+constexpr size_t kWfTuneWords = 128;  // the sort tuner's books (rt_kernels.hip: SortChoice)
 constexpr size_t kWfCursorWords = 8 * 1024;  // 8 cursors, 4 KB apart (rt_kernels.hip: kShards x kCursorStride)
 constexpr size_t kWfBinWords = 2 * 4096;     // histogram + cursors of the ray-sorting cells (rt_device.h: kBins)
 constexpr size_t kWfBytesPerPath = 16 + 16 + 16 + 16 + 8 + 4 + 4 + 8 + 2;
@@ -98,12 +99,13 @@ struct WavefrontBuffers {
     uint32_t *retry = nullptr;  // 2 x capacity: (slot, hit position) of the rays whose walk of the four-child tree ran out of stack
     uint16_t *bin = nullptr;  // capacity: ray-sorting cell of each entry of the queue being filled
     uint32_t *binhist = nullptr;  // kWfBinWords: histogram of the cells, then their cursors
-    int sort = 0;             // regroup the rays of the later bounces by cell: 0 never, 1 every bounce, 2 where a bounce's
-                              // survivors have lost their coherence (decided on the device, see wf_shade)
-    uint32_t sort_min_pairs = 1u << 20;  // mode 2: queues with fewer neighbouring survivors are not worth three launches
+    int sort = 0;             // regroup the rays of the later bounces by cell: 0 never, 1 every bounce, 2 the bounces for
+                              // which it was measured to pay (decided on the device, see SortChoice in rt_kernels.hip)
+    uint32_t sort_min_rays = 1u << 20;  // mode 2: shorter queues are not worth three launches
+    uint32_t *tuner = nullptr;  // kWfTuneWords words, zero when allocated and then the tuner's own (mode 2)
     bool wide = true;         // wf_extend walks the four-child tree
     int stack_limit = 24;     // entries of the traversal stack the wide walk may use (the kernel caps it at its own 20; less only in tests)
-    uint32_t *qcount = nullptr; // kWfCountWords words: queue lengths, retry count, coherence probes (device)
+    uint32_t *qcount = nullptr; // kWfCountWords words: queue lengths, retry count (device)
     uint32_t *cursors = nullptr; // work cursors of the extend kernel, kWfCursorWords words
 };
 

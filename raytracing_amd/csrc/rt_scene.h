@@ -27,7 +27,7 @@ struct rt_scene {
     bool wide_tree = true;   // wavefront pipeline: wf_extend walks the four-child tree
     int stack_limit = rtd::kStack;
     int sort_rays = 0;       // wavefront pipeline: regroup the rays of the later bounces by cell (0 never, 1 always, 2 adaptive)
-    uint32_t sort_min_pairs = 1u << 20;
+    uint32_t sort_min_rays = 1u << 20;
     uint32_t nmat = 0;
     rt::KernelTimer timer;
     uint64_t host_segments = 0;  // segments of launches whose ray count the host knows (one per ray)

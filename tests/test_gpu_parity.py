@@ -309,15 +309,16 @@ def test_wavefront_multi_pass_matches_single_pass_and_oracle(scene_dir, oracle_m
 ])
 def test_wavefront_ray_sorting_changes_no_result(scene_dir, oracle_mod, monkeypatch, name, kw, W, H, depth):
     """From the second bounce on the wavefront pipeline can regroup the ray queue by the cell of the ray origin:
-    RT_WF_SORT=1 on every bounce, =2 on the bounces whose survivors have lost their coherence (decided on the
-    device from a probe the shading kernel counts; the default for scenes larger than the L2 caches), =0 never.
+    RT_WF_SORT=1 on every bounce, =2 on the bounces a tuner on the device finds it pays for (it times both ways
+    over the first passes: the several-pass renders below go through all its states; the default for scenes
+    larger than the L2 caches), =0 never.
     Only the order in which rays are traced changes: every path's arithmetic is its own and sums are taken per
     slot, so all three renders are bit-equal, with equal segment and light-test counts, one pass or several."""
     import raytracing_amd as rt
     host, _, orc = _load(scene_dir, oracle_mod, name, W, H, **kw)
     ref, c_o = orc.render(W, H, 6, max_depth=depth, rng_mode=1, seed=21, spp_begin=2)
     outs = {}
-    monkeypatch.setenv("RT_WF_SORT_MIN_PAIRS", "0")              # the adaptive mode ignores small queues otherwise
+    monkeypatch.setenv("RT_WF_SORT_MIN_RAYS", "0")               # the tuned mode ignores short queues otherwise
     for flag in ("0", "1", "2"):
         monkeypatch.setenv("RT_WF_SORT", flag)
         monkeypatch.delenv("RT_WF_PATHS", raising=False)
