@@ -426,7 +426,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? kWideWaves : 1) void wf_extend(DevSc
     if (segs) add_counters(S, segs, st, 0u, COUNT);
     if (tune && last_workgroup(tune)) {  // the tuner: file this bounce's cost, decide the next bounce
         const unsigned long long now = wall_clock64(), mark = *reinterpret_cast<const unsigned long long *>(tune);
-        if (bounce >= 2u && bounce < kTuneBounces && count) {
+        if (!COUNT && bounce >= 2u && bounce < kTuneBounces && count) {  // (the counting instantiation is slower: not filed)
             uint32_t *cost = tune_bounce(tune, bounce) + (hit_by_slot ? 1 : 0);
             const unsigned long long m = ((now - mark) << 20) / count;
             const uint32_t v = m > 0xFFFFFFFFull ? 0xFFFFFFFFu : (m ? (uint32_t)m : 1u), old = *cost;
