@@ -136,7 +136,7 @@ void free_wavefront(rt_scene *s) {
 // paths (90 B each with the queues: 24 GB of the 288 GB), never more than the call renders.  The
 // deeper bounces of a pass keep only a few percent of its paths alive, and every launch pays a ramp
 // and a drain of about one ray's duration, so fewer, larger launches win: 16M -> 3424, 32M -> 3656,
-// 64M -> 3763, 128M -> 3827 Mrays/s on the million-triangle 1080p depth-8 workload in round 1; with
+// 64M -> 3763, 128M -> 3827 Mrays/s on the million-triangle 1080p depth-8 workload with unsorted rays; with
 // sorted rays 64M -> 5110, 128M -> 5229, 256M -> 5328, 512M -> 5342.  RT_WF_PATHS overrides the path budget.
 uint32_t wavefront_slots(uint32_t npix, uint32_t spp_count) {
     uint64_t target = 256u << 20;

@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-SURVEY_TABLE = {  # seed: (raw[4], uniform bits[3], normal bits[3], engine draws for the 3 normals, ui2, ui12)
+LIBSTDCXX_TABLE = {  # seed: (raw[4], uniform bits[3], normal bits[3], engine draws for the 3 normals, ui2, ui12)
     0: ([48271, 182605794, 1291394886, 1914720637], [0x37bc8e00, 0x3dae257e, 0x3f19f23f],
         [0x3f642e37, 0xc01f238b, 0x3f63ed65], 10, [0, 0, 1, 1], [0, 1, 7, 10]),
     64037: ([943646380, 478772463, 1754036106, 239122457], [0x3ee0fb9b, 0x3e644be7, 0x3f5118ef],
@@ -45,7 +45,7 @@ def main():
         kat[str(seed)] = dict(raw=[int(x) for x in k["raw"]], uni_bits=[int(x) for x in k["uni"].view(np.uint32)],
                               nrm_bits=[int(x) for x in k["nrm"].view(np.uint32)], nrm_draws=int(k["nrm_draws"]),
                               ui2=[int(x) for x in k["ui2"]], ui12=[int(x) for x in k["ui12"]])
-    for seed, (raw, uni, nrm, draws, ui2, ui12) in SURVEY_TABLE.items():
+    for seed, (raw, uni, nrm, draws, ui2, ui12) in LIBSTDCXX_TABLE.items():
         e = kat[str(seed)]
         assert (e["raw"], e["uni_bits"], e["nrm_bits"], e["nrm_draws"], e["ui2"], e["ui12"]) == \
             (raw, uni, nrm, draws, ui2, ui12), "oracle RNG disagrees with the recorded table for seed %d" % seed
