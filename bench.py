@@ -47,6 +47,12 @@ def main():
     ap.add_argument("--no-primary", action="store_true")
     args = ap.parse_args()
 
+    # Standard output carries the one JSON line and nothing else: libraries that write to file descriptor 1
+    # themselves (RCCL prints a version banner there when its communicator opens) are sent to standard error.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -279,7 +285,9 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu,
     }
     out.update(extra)
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(result_fd, (json.dumps(out) + "\n").encode())
+    os.close(result_fd)
     scene.close()
     if use_dist:
         dist.destroy_process_group()
