@@ -144,6 +144,9 @@ typedef struct rt_scene_stats {
      * heuristic wanted, i.e. the scene is close to the triangle limit. */
     uint32_t height_capped_splits;
     uint32_t nprims; /* analytic primitives */
+    /* triangle records of the flattened structure: ntri plus the pad records that keep every two-triangle
+     * leaf inside one 128-byte line (rt_flat_get) */
+    uint32_t ntri_records;
 } rt_scene_stats;
 
 /* Counters accumulated on the device by the launches since the last rt_counters_reset:
@@ -202,19 +205,21 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out);
 void rt_scene_destroy(rt_scene *s);
 int rt_scene_get_stats(const rt_scene *s, rt_scene_stats *out);
 /* Copies of the flattened structure for checkers: the node grid (origin xyz, cell xyz), nodes
- * (nnodes * 8 words, layout under rt_flat_get), triangles in leaf order (ntri * 16 floats).  Any
+ * (nnodes * 8 words, layout under rt_flat_get), triangle records in leaf order (ntri_records * 16 floats).  Any
  * pointer may be NULL. */
 int rt_scene_get_flat(const rt_scene *s, float grid[6], uint32_t *nodes, float *tris);
 
 /* Host-only view of the same build (no GPU call), for tools and checkers: builds the
  * acceleration structure of `desc` and hands out the flattened arrays exactly as rt_scene_create
- * would upload them.  info[0] = node count, [1] = triangle count, [2] = light count,
+ * would upload them.  info[0] = node count, [1] = triangle record count, [2] = light count,
  * [3] = tree height (inner levels).  grid: origin xyz then cell xyz of the 16-bit node grid.
  * nodes: nnodes*8 words; words 0-2 = left child's box (one word per axis: lo | hi << 16, plane =
  * origin + q * cell, rounded outward), 3-5 = right child's box, 6-7 = child references (>= 0 node
- * index, < 0 leaf: ~ref = first << 3 | count-1).  tris: ntri*16 floats, leaf order (A, AB, AC,
- * cross(AB,AC), loader id, material, 2/|N|, 0).  lights: leaf-order positions of the emissive
- * triangles in loader order.  Any pointer may be NULL. */
+ * index, < 0 leaf: ~ref = first << 3 | count-1).  tris: info[1]*16 floats, leaf order (A, AB, AC,
+ * cross(AB,AC), loader id, material, 2/|N|, 0).  A leaf of two triangles starts on an even record (both
+ * in one 128-byte line); the record skipped for that is a pad no leaf names (A = 3e30, loader id =
+ * RT_MISS_ID), so info[1] >= ntri.  lights: leaf-order positions of the emissive triangles in loader
+ * order.  Any pointer may be NULL. */
 typedef struct rt_flat rt_flat;
 int rt_flat_build(const rt_scene_desc *desc, rt_flat **out);
 int rt_flat_get(const rt_flat *f, uint32_t info[4], float grid[6], uint32_t *nodes, float *tris,

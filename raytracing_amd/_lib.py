@@ -36,7 +36,7 @@ class SceneDesc(C.Structure):
 class SceneStats(C.Structure):
     _fields_ = [("ntri", C.c_uint32), ("nlights", C.c_uint32), ("nnodes", C.c_uint32), ("tree_height", C.c_uint32),
                 ("build_seconds", C.c_double), ("device_bytes", C.c_uint64), ("height_capped_splits", C.c_uint32),
-                ("nprims", C.c_uint32)]
+                ("nprims", C.c_uint32), ("ntri_records", C.c_uint32)]
 
 
 class Counters(C.Structure):

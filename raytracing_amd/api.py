@@ -179,13 +179,13 @@ class Scene:
         check(_lib.lib().rt_scene_get_stats(self._h, C.byref(s)))
         return dict(ntri=s.ntri, nlights=s.nlights, nnodes=s.nnodes, tree_height=s.tree_height,
                     build_seconds=s.build_seconds, device_bytes=int(s.device_bytes),
-                    height_capped_splits=s.height_capped_splits, nprims=s.nprims)
+                    height_capped_splits=s.height_capped_splits, nprims=s.nprims, ntri_records=s.ntri_records)
 
     def flat(self):
         st = self.stats()
         grid = np.empty(6, dtype=np.float32)
         nodes = np.empty((st["nnodes"], 8), dtype=np.uint32)
-        tris = np.empty((st["ntri"], 16), dtype=np.float32)
+        tris = np.empty((st["ntri_records"], 16), dtype=np.float32)
         check(_lib.lib().rt_scene_get_flat(self._h, _p(grid), _p(nodes), _p(tris)))
         return grid, nodes, tris
 

@@ -66,6 +66,8 @@ struct BNode {
     int32_t child[2];  // >= 0: BNode index; < 0: ~((first << 3) | (count - 1))
 };
 
+constexpr uint32_t kPadRecord = 0xFFFFFFFFu;  // FlatTree::order entry of a record that holds no triangle
+
 inline int32_t leaf_ref(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
 
 // Inner levels a range of n triangles needs at least (leaves hold <= kMaxLeafTris).
@@ -308,8 +310,39 @@ void build_tree(const float *verts, const uint32_t *which, uint32_t n, FlatTree 
         out.sah_nodes = n ? en : 0.0;
         out.sah_tris = n ? et : 0.0;
     }
-    out.order.resize(n);
-    for (uint32_t k = 0; k < n; ++k) out.order[k] = B.prims[k].id;
+    if (!which && n > kMaxLeafTris) {
+        // Main tree: a two-triangle leaf starts on an even record, so that its 2 x 64 bytes are ONE 128-byte
+        // cache line (the trace kernel fetches both triangles in one pass; nearly every triangle fetch of a
+        // large scene goes to memory, and a pair across two lines cost two of them: -2.8 % of the trace
+        // kernel on the million-triangle scene).  A record skipped for that is a pad (kPadRecord in `order`):
+        // no leaf names it and it can never be hit.  The order of the triangles does not change.
+        std::vector<uint8_t> cntAt(n, 0);
+        for (uint32_t k = 0; k < nnodes; ++k)
+            for (int c = 0; c < 2; ++c) {
+                const int32_t ref = B.nodes[k].child[c];
+                if (ref < 0) cntAt[(uint32_t)~ref >> 3] = (uint8_t)(((uint32_t)~ref & 7u) + 1u);
+            }
+        std::vector<uint32_t> newPos(n);
+        uint32_t pos = 0;
+        for (uint32_t p = 0; p < n;) {
+            const uint32_t cnt = cntAt[p];
+            if (cnt == 0) throw std::runtime_error("internal: leaves do not tile the triangle range");
+            if (cnt == 2 && (pos & 1u)) ++pos;
+            for (uint32_t j = 0; j < cnt; ++j) newPos[p + j] = pos + j;
+            pos += cnt;
+            p += cnt;
+        }
+        for (uint32_t k = 0; k < nnodes; ++k)
+            for (int c = 0; c < 2; ++c) {
+                const int32_t ref = B.nodes[k].child[c];
+                if (ref < 0) B.nodes[k].child[c] = leaf_ref(newPos[(uint32_t)~ref >> 3], ((uint32_t)~ref & 7u) + 1u);
+            }
+        out.order.assign(pos, kPadRecord);
+        for (uint32_t k = 0; k < n; ++k) out.order[newPos[k]] = B.prims[k].id;
+    } else {
+        out.order.resize(n);
+        for (uint32_t k = 0; k < n; ++k) out.order[k] = B.prims[k].id;
+    }
 
     // Node boxes go to the device on a 16-bit grid spanning the (padded) bounds of the triangles:
     //   plane = grid_origin + q * grid_cell,  q in [0, 65535],
@@ -526,13 +559,21 @@ void build_flat_scene(const rt_scene_desc &desc, FlatScene &out) {
     }
 
     // Triangles in leaf order, with the derived data of Triangle::update (main.cpp:527-536).
-    out.tris.assign((size_t)std::max<uint32_t>(n, 1) * 16, 0.f);
+    const uint32_t nslots = (uint32_t)tree.order.size();
+    out.nslots = nslots;
+    out.tris.assign((size_t)std::max<uint32_t>(nslots, 1) * 16, 0.f);
     std::vector<uint32_t> posOfId(n);
 #pragma omp parallel for schedule(static)
-    for (int64_t k = 0; k < (int64_t)n; ++k) {
+    for (int64_t k = 0; k < (int64_t)nslots; ++k) {
         const uint32_t id = tree.order[k];
+        float *q = &out.tris[(size_t)k * 16];
+        if (id == kPadRecord) {  // never hit, like the dummy of an empty scene below
+            q[0] = q[1] = q[2] = 3.0e30f;
+            q[12] = bits_to_float(RT_MISS_ID);
+            continue;
+        }
         posOfId[id] = (uint32_t)k;
-        triangle_record(desc, id, &out.tris[(size_t)k * 16]);
+        triangle_record(desc, id, q);
     }
     if (n == 0) {  // one never-hit dummy so leaf_ref(0, 1) stays in bounds
         float *q = &out.tris[0];
@@ -612,7 +653,7 @@ int rt_flat_get(const rt_flat *f, uint32_t info[4], float grid[6], uint32_t *nod
     const rt::FlatScene &s = f->flat;
     if (info) {
         info[0] = s.nnodes;
-        info[1] = s.ntri;
+        info[1] = s.nslots;
         info[2] = (uint32_t)s.lights.size();
         info[3] = s.tree_height;
     }
@@ -622,7 +663,7 @@ int rt_flat_get(const rt_flat *f, uint32_t info[4], float grid[6], uint32_t *nod
             grid[3 + a] = s.grid_cell[a];
         }
     if (nodes) std::memcpy(nodes, s.nodes.data(), (size_t)s.nnodes * 8 * sizeof(uint32_t));
-    if (tris) std::memcpy(tris, s.tris.data(), (size_t)s.ntri * 16 * sizeof(float));
+    if (tris) std::memcpy(tris, s.tris.data(), (size_t)s.nslots * 16 * sizeof(float));
     if (lights && !s.lights.empty()) std::memcpy(lights, s.lights.data(), s.lights.size() * sizeof(uint32_t));
     return RT_OK;
 }

@@ -327,7 +327,8 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
     }
     v.mats = s->d_mats;
     v.prims = s->d_prims;
-    v.ntri = f.ntri;
+    v.ntri = f.nslots;
+    v.npad = f.nslots - f.ntri;
     v.nprims = f.nprims;
     v.counters = s->d_counters;
     v.nlights = (uint32_t)f.lights.size();
@@ -353,7 +354,7 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
         // scene) and is found out by measuring on the device (mode 2: the tuner of rt_kernels.hip).
         // RT_WF_SORT=0 / 1 / 2 forces never / every bounce / tuned; RT_WF_SORT_MIN_RAYS lowers the queue length
         // below which mode 2 never sorts (tests).
-        const size_t tree_bytes = (size_t)f.nwide * 48u + (size_t)f.ntri * 64u;
+        const size_t tree_bytes = (size_t)f.nwide * 48u + (size_t)f.nslots * 64u;
         s->sort_rays = tree_bytes >= ((size_t)32 << 20) ? 2 : 0;
         if (const char *e = std::getenv("RT_WF_SORT")) {
             const int m = std::atoi(e);
@@ -402,6 +403,7 @@ void rt_scene_destroy(rt_scene *s) {
 int rt_scene_get_stats(const rt_scene *s, rt_scene_stats *out) {
     if (!s || !out) return fail(RT_ERR_INVALID, "rt_scene_get_stats: null argument");
     out->ntri = s->flat->ntri;
+    out->ntri_records = s->flat->nslots;
     out->nlights = (uint32_t)s->flat->lights.size();
     out->nnodes = s->flat->nnodes;
     out->tree_height = s->flat->tree_height;
@@ -420,7 +422,7 @@ int rt_scene_get_flat(const rt_scene *s, float grid[6], uint32_t *nodes, float *
             grid[3 + a] = s->flat->grid_cell[a];
         }
     if (nodes) std::memcpy(nodes, s->flat->nodes.data(), (size_t)s->flat->nnodes * 8 * sizeof(uint32_t));
-    if (tris) std::memcpy(tris, s->flat->tris.data(), (size_t)s->flat->ntri * 16 * sizeof(float));
+    if (tris) std::memcpy(tris, s->flat->tris.data(), (size_t)s->flat->nslots * 16 * sizeof(float));
     return RT_OK;
 }
 

@@ -125,7 +125,8 @@ struct DevScene {
     const float4 *prims;      // 3 x float4 per analytic primitive: (position.xyz, bits(type)), rotation xyzw, (param.xyz, bits(material))
     unsigned long long *counters;  // kCounterShards x kCounterStride; per shard [0] segments [1] nodes [2] tri tests [3] light tests
     uint32_t nlights, nmats;
-    uint32_t ntri, nprims;               // a hit index >= ntri names analytic primitive (index - ntri)
+    uint32_t ntri, nprims;               // ntri = triangle RECORDS (pads included): a hit index >= ntri names analytic primitive (index - ntri)
+    uint32_t npad;                       // pad records among them: the caller sees primitive k as (loader triangle count) + k
     uint32_t light_tree;                 // nonzero: the launchers pick the kernels whose light_pdf walks lnodes; the value is that tree's height
     float grid_origin[3], grid_cell[3];  // node-box plane = origin + q * cell, q a 16-bit integer
     float lgrid_origin[3], lgrid_cell[3];  // the same for lnodes

@@ -77,7 +77,7 @@ struct FlatScene {
     uint32_t nwide = 0;
     float grid_origin[3] = {0.f, 0.f, 0.f};
     float grid_cell[3] = {1.f, 1.f, 1.f};
-    std::vector<float> tris;        // ntri * 16
+    std::vector<float> tris;        // nslots * 16
     std::vector<uint32_t> lights;   // leaf-order positions of emissive triangles, loader order
     // tree over the light triangles only (same node format, its own grid) and their records in that
     // tree's leaf order: a triangle record whose word 12 = index in `lights`, word 13 = lights[index]
@@ -93,6 +93,7 @@ struct FlatScene {
     uint32_t nprims = 0;
     uint32_t nnodes = 0;
     uint32_t ntri = 0;
+    uint32_t nslots = 0;  // records in `tris`: the ntri triangles in leaf order plus the pad records between them
     uint32_t tree_height = 0;
     uint32_t capped_splits = 0;
     double sah_nodes = 0.0, sah_tris = 0.0;

@@ -60,7 +60,7 @@ __device__ __forceinline__ void add_counters(const DevScene &S, uint32_t segs, c
 
 // Primitive id reported to the caller: the loader-order id of a triangle, ntri + k for analytic primitive k.
 __device__ __forceinline__ uint32_t tri_loader_id(const DevScene &S, int tri) {
-    if ((uint32_t)tri >= S.ntri) return (uint32_t)tri;
+    if ((uint32_t)tri >= S.ntri) return (uint32_t)tri - S.npad;
     return __float_as_uint(S.tris[4 * (size_t)tri + 3].x);
 }
 
