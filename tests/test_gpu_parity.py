@@ -871,3 +871,44 @@ def test_analytic_primitives(scene_dir, oracle_mod):
             assert gpu.counters()["segments"] == c_o["segments"]
         gpu.close()
         orc.close()
+
+
+def test_analytic_primitive_ids_with_pad_records(scene_dir, oracle_mod):
+    """A scene whose triangle array holds pad records (two-triangle leaves start on even records), plus analytic
+    primitives: on the device a primitive's index lies behind the RECORDS, the caller must still see it as
+    (loader triangle count) + k, and triangles as their loader ids.  Hit ids and distances bit for bit against
+    the oracle for camera rays and random rays; a counter-mode render on both pipelines within 1e-5."""
+    import raytracing_amd as rt
+    W, H = 96, 72
+    base = rt.load_gltf(make_scene(scene_dir, "spheres1m", n_spheres=10, subdiv=2, ground=8), W, H)
+    types = base.materials["type"]
+    emits = np.linalg.norm(base.materials["emission"], axis=1) > 1e-4
+    pick = [int(np.flatnonzero((types == t) & ~emits)[0]) for t in (0, 2, 1)]
+    rng = np.random.RandomState(7)
+    prims = _analytic_prims(rt, rng, pick)
+    host = rt.HostScene(base.tri_verts, base.tri_material, base.materials, base.camera, prims=prims)
+    gpu = rt.Scene(host, device=0)
+    d = host.as_dict()
+    orc = oracle_mod.OracleScene(d["tri_verts"], d["tri_material"], d["materials"], d["camera"], d["background"], d["prims"])
+    ntri = host.tri_material.shape[0]
+    st = gpu.stats()
+    assert st["ntri"] == ntri and st["ntri_records"] > ntri and st["nprims"] == 7
+    ids_o, t_o, tie, _ = orc.trace_primary(W, H)
+    ids_g, t_g = gpu.trace_primary(W, H)
+    _compare_hits(ids_g, t_g, ids_o, t_o, tie)
+    n = 30000
+    o = rng.uniform(-1.5, 1.5, size=(n, 3)).astype(np.float32)
+    dirs = rng.normal(size=(n, 3))
+    dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float32)
+    ids_o, t_o, tie, _ = orc.intersect(o, dirs, use_bvh=True)
+    ids_g, t_g = gpu.intersect(o, dirs)
+    _compare_hits(ids_g, t_g, ids_o, t_o, tie)
+    hit = ids_g != 0xFFFFFFFF
+    assert (ids_g[hit] < ntri + 7).all() and (ids_g[hit] >= ntri).any() and (ids_g[hit] < ntri).any()
+    ref, c_o = orc.render(W, H, 3, max_depth=6, rng_mode=1, seed=9)
+    for pipe in (rt.PIPE_MEGAKERNEL, rt.PIPE_WAVEFRONT):
+        gpu.reset_counters()
+        _assert_close(gpu.render(W, H, 3, max_depth=6, rng_mode=1, seed=9, pipeline=pipe), ref)
+        assert gpu.counters()["segments"] == c_o["segments"]
+    gpu.close()
+    orc.close()
