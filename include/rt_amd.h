@@ -307,6 +307,8 @@ int rt_multi_create(const rt_scene_desc *desc, const int *devices, int ndev, rt_
 void rt_multi_destroy(rt_multi *m);
 int rt_multi_device_count(const rt_multi *m);
 rt_scene *rt_multi_scene(rt_multi *m, int i);
+/* GPU g's part of spp_count samples split over ndev GPUs (offset relative to spp_begin, and length); an empty
+ * range (0, 0) when ndev <= 0 or g is outside [0, ndev). */
 void rt_multi_sample_range(uint32_t spp_count, int ndev, int g, uint32_t *begin, uint32_t *count);
 int rt_multi_render(rt_multi *m, uint32_t width, uint32_t height, uint32_t spp_begin, uint32_t spp_count,
                     uint32_t max_depth, uint32_t seed, int pipeline, float *radiance_sum);

@@ -159,22 +159,33 @@ int ensure_wavefront(rt_scene *s, uint32_t npix, uint32_t slots) {
     RT_HIP(hipDeviceSynchronize());
     free_wavefront(s);
     rt::WavefrontBuffers &w = s->wf;
-    RT_HIP(dev_alloc(s, &w.ray, (size_t)cap * 2));
-    RT_HIP(dev_alloc(s, &w.c, (size_t)cap));
-    RT_HIP(dev_alloc(s, &w.lum, (size_t)cap));
-    RT_HIP(dev_alloc(s, &w.hit, (size_t)cap));
-    RT_HIP(dev_alloc(s, &w.queue[0], (size_t)cap));
-    RT_HIP(dev_alloc(s, &w.queue[1], (size_t)cap));
-    RT_HIP(dev_alloc(s, &w.bin, (size_t)cap));
-    RT_HIP(dev_alloc(s, &w.retry, (size_t)cap * 2));
-    RT_HIP(dev_alloc(s, &w.binhist, rt::kWfBinWords));
-    RT_HIP(hipMemset(w.binhist, 0, rt::kWfBinWords * sizeof(uint32_t)));
-    RT_HIP(dev_alloc(s, &w.qcount, rt::kWfCountWords));
-    RT_HIP(hipMemset(w.qcount, 0, rt::kWfCountWords * sizeof(uint32_t)));
-    RT_HIP(dev_alloc(s, &w.cursors, rt::kWfCursorWords));
-    RT_HIP(hipMemset(w.cursors, 0, rt::kWfCursorWords * sizeof(uint32_t)));
-    RT_HIP(dev_alloc(s, &w.tuner, rt::kWfTuneWords));
-    RT_HIP(hipMemset(w.tuner, 0, rt::kWfTuneWords * sizeof(uint32_t)));
+    // capacity first: if an allocation below fails, free_wavefront releases what was allocated with the sizes it
+    // was allocated with (and accounted under), and leaves the scene without path records
+    w.capacity = cap;
+    hipError_t e = hipSuccess;
+#define RT_WF(call) \
+    if (e == hipSuccess) e = (call)
+    RT_WF(dev_alloc(s, &w.ray, (size_t)cap * 2));
+    RT_WF(dev_alloc(s, &w.c, (size_t)cap));
+    RT_WF(dev_alloc(s, &w.lum, (size_t)cap));
+    RT_WF(dev_alloc(s, &w.hit, (size_t)cap));
+    RT_WF(dev_alloc(s, &w.queue[0], (size_t)cap));
+    RT_WF(dev_alloc(s, &w.queue[1], (size_t)cap));
+    RT_WF(dev_alloc(s, &w.bin, (size_t)cap));
+    RT_WF(dev_alloc(s, &w.retry, (size_t)cap * 2));
+    RT_WF(dev_alloc(s, &w.binhist, rt::kWfBinWords));
+    RT_WF(hipMemset(w.binhist, 0, rt::kWfBinWords * sizeof(uint32_t)));
+    RT_WF(dev_alloc(s, &w.qcount, rt::kWfCountWords));
+    RT_WF(hipMemset(w.qcount, 0, rt::kWfCountWords * sizeof(uint32_t)));
+    RT_WF(dev_alloc(s, &w.cursors, rt::kWfCursorWords));
+    RT_WF(hipMemset(w.cursors, 0, rt::kWfCursorWords * sizeof(uint32_t)));
+    RT_WF(dev_alloc(s, &w.tuner, rt::kWfTuneWords));
+    RT_WF(hipMemset(w.tuner, 0, rt::kWfTuneWords * sizeof(uint32_t)));
+#undef RT_WF
+    if (e != hipSuccess) {
+        free_wavefront(s);
+        return hip_fail("wavefront pipeline: allocating the path records", e);
+    }
     w.capacity = cap;
     w.sort = s->sort_rays;
     w.sort_min_rays = s->sort_min_rays;

@@ -442,7 +442,9 @@ __global__ __launch_bounds__(kBlock, WIDE ? kWideWaves : 1) void wf_extend(DevSc
                 if ((tune[3]++ & 63u) == 63u) d ^= 1u;
             }
         }
-        tune_bounce(tune, next)[2] = d;
+        // Only a bounce with books of its own gets a decision.  (tune_bounce() clamps: the write for bounce
+        // kTuneBounces would land in the last entry, whose decision the kernels of THAT bounce are still reading.)
+        if (next < kTuneBounces) tune_bounce(tune, next)[2] = d;
     }
 }
 

@@ -159,6 +159,11 @@ rt_scene *rt_multi_scene(rt_multi *m, int i) {
 }
 
 void rt_multi_sample_range(uint32_t spp_count, int ndev, int g, uint32_t *begin, uint32_t *count) {
+    if (ndev <= 0 || g < 0 || g >= ndev) {  // no such GPU: an empty range
+        if (begin) *begin = 0u;
+        if (count) *count = 0u;
+        return;
+    }
     // contiguous split; the first spp_count % ndev GPUs take one sample more
     const uint32_t base = spp_count / (uint32_t)ndev, extra = spp_count % (uint32_t)ndev, ug = (uint32_t)g;
     if (begin) *begin = ug * base + (ug < extra ? ug : extra);

@@ -340,6 +340,35 @@ def test_wavefront_ray_sorting_changes_no_result(scene_dir, oracle_mod, monkeypa
             _assert_bits_equal(gpu.render(W, H, 6, max_depth=depth, rng_mode=1, seed=21, spp_begin=2, pipeline=rt.PIPE_WAVEFRONT), outs["0"])
 
 
+def test_ray_sorting_tuner_on_paths_deeper_than_its_books(scene_dir, oracle_mod, monkeypatch):
+    """The tuner keeps books for 30 bounces; deeper bounces are never sorted, and the decision word of the last
+    booked bounce must not change while that bounce's kernels read it.  Closed box, depth 34, three passes (so
+    the tuner has measured bounce 29 unsorted and tries it sorted): bit-equal to the unsorted render, equal
+    segment counts, and paths really reach the bounces beyond the books."""
+    import raytracing_amd as rt
+    W, H, depth = 128, 96, 34
+    host, _, orc = _load(scene_dir, oracle_mod, "cornell", W, H)
+    monkeypatch.setenv("RT_WF_SORT_MIN_RAYS", "0")
+    monkeypatch.setenv("RT_WF_PATHS", str(2 * W * H))
+    outs, segs = {}, {}
+    for flag in ("0", "2", "1"):
+        monkeypatch.setenv("RT_WF_SORT", flag)
+        with rt.Scene(host, device=0) as gpu:
+            gpu.reset_counters()
+            outs[flag] = gpu.render(W, H, 6, max_depth=depth, rng_mode=1, seed=4, pipeline=rt.PIPE_WAVEFRONT)
+            segs[flag] = gpu.counters()["segments"]
+            again = gpu.render(W, H, 6, max_depth=depth, rng_mode=1, seed=4, pipeline=rt.PIPE_WAVEFRONT)
+            _assert_bits_equal(again, outs[flag])                  # the tuner's state differs, the sums do not
+    _assert_bits_equal(outs["2"], outs["0"])
+    _assert_bits_equal(outs["1"], outs["0"])
+    assert segs["0"] == segs["1"] == segs["2"]
+    ref, c_o = orc.render(W, H, 6, max_depth=depth, rng_mode=1, seed=4)
+    assert c_o["segments"] == segs["0"]
+    _assert_close(outs["0"], ref)
+    shallow, c_s = orc.render(W, H, 6, max_depth=30, rng_mode=1, seed=4)
+    assert c_o["segments"] > c_s["segments"]                       # some paths are longer than 30 segments
+
+
 @pytest.mark.parametrize("name,kw,W,H,depth", [
     ("cornell", {}, 128, 96, 8),
     ("spheres1m", {"n_spheres": 40, "subdiv": 2, "ground": 16}, 100, 75, 8),
