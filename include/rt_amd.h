@@ -70,6 +70,32 @@ extern "C" {
 #define RT_MAX_TREE_HEIGHT 24
 #define RT_MAX_TRIANGLES (2u << RT_MAX_TREE_HEIGHT)
 
+/* Where the reference's answer depends on the ORDER in which its own tree (BVH::build, main.cpp:552-558,
+ * 608-686) is walked (BVH::intersect, main.cpp:560-605):
+ *   - two primitives at exactly the same distance -- coincident faces, a box standing on a floor, a ray through
+ *     an edge shared by two triangles: the first one met wins (strict `<`, main.cpp:566-567, 589-590, 598-599);
+ *   - a ray lying in the plane of a triangle: a "hit" at distance NaN, kept when it is the first of its leaf
+ *     (main.cpp:483, 566);  a hit at t >= INF, likewise;
+ *   - subtrees cut by `distance < minDistance` on boxes of twice their size (main.cpp:174-177, 571, 587, 596).
+ * RT_HITS_REFERENCE_ORDER: the library builds that very tree on the host (the reference's full-sweep SAH with
+ * its sequence of std::sort calls, leaves of four, pre-order numbering) next to its own and resolves these
+ * cases as the reference does: the closest-hit calls and the RT_RNG_REFERENCE render walk the reference's
+ * tree in the reference's order for EVERY ray (all of the above reproduced); the RT_RNG_COUNTER pipelines trace
+ * on the library's own tree and hand the rays that met two primitives at the best distance to that walk (equal
+ * distances reproduced).  Available for scenes the reference itself can hold: at most 65535 primitives and
+ * tree nodes (its ids are uint16_t, main.cpp:541-544), no unsplittable node of more than four primitives
+ * (main.cpp:675-679 stores an out-of-range index there) and a tree of at most 64 levels; it is the default for
+ * those (environment RT_HIT_ORDER=leaf at rt_scene_create overrides).
+ * RT_HITS_REFERENCE_WALK: as RT_HITS_REFERENCE_ORDER, and the RT_RNG_COUNTER megakernel too sends every ray through
+ * the reference's walk (slow; a validation aid: its ray-segment counts then equal the CPU path's even where a path
+ * meets a NaN hit).  The wavefront pipeline behaves as under RT_HITS_REFERENCE_ORDER.
+ * RT_HITS_LEAF_ORDER: the library's own tree only; of two primitives at exactly the same distance the one
+ * earlier in the library's leaf order wins; NaN distances and t >= INF are misses.  The only mode for larger
+ * scenes. */
+#define RT_HITS_LEAF_ORDER 0
+#define RT_HITS_REFERENCE_ORDER 1
+#define RT_HITS_REFERENCE_WALK 2
+
 #define RT_MISS_ID 0xFFFFFFFFu /* prim_id of a ray that hits nothing */
 #define RT_INF 10000.0f        /* t of a ray that hits nothing (INF, main.cpp:23) */
 
@@ -147,6 +173,9 @@ typedef struct rt_scene_stats {
     /* triangle records of the flattened structure: ntri plus the pad records that keep every two-triangle
      * leaf inside one 128-byte line (rt_flat_get) */
     uint32_t ntri_records;
+    uint32_t hit_order;      /* RT_HITS_*: how order-dependent hits are resolved now */
+    uint32_t ref_tree_nodes; /* nodes / deepest level of the reference's own tree; 0 when the scene is beyond */
+    uint32_t ref_tree_depth; /* the reference's limits (rt_scene_set_hit_order then reports why) */
 } rt_scene_stats;
 
 /* Counters accumulated on the device by the launches since the last rt_counters_reset:
@@ -204,6 +233,9 @@ void rt_host_scene_free(rt_host_scene *hs);
 int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out);
 void rt_scene_destroy(rt_scene *s);
 int rt_scene_get_stats(const rt_scene *s, rt_scene_stats *out);
+/* Selects RT_HITS_LEAF_ORDER / RT_HITS_REFERENCE_ORDER / RT_HITS_REFERENCE_WALK for the later calls on this scene.  RT_ERR_LIMIT with the
+ * reason in rt_last_error() when the reference's own tree is not available for the scene. */
+int rt_scene_set_hit_order(rt_scene *s, int order);
 /* Copies of the flattened structure for checkers: the node grid (origin xyz, cell xyz), nodes
  * (nnodes * 8 words, layout under rt_flat_get), triangle records in leaf order (ntri_records * 16 floats).  Any
  * pointer may be NULL. */
@@ -239,6 +271,13 @@ int rt_flat_get_light_tree(const rt_flat *f, uint32_t info[2], float grid[6], ui
  * children << 28; words 8-11 = child references (>= 0 index of a wide node, < 0 a leaf as in rt_flat_get,
  * 0x7FFFFFFF unused).  Every child box contains the box the two-child tree holds for the same subtree. */
 int rt_flat_get_wide(const rt_flat *f, uint32_t *nwide, uint32_t *nodes);
+/* The reference's own tree of the same scene (BVH::build, main.cpp:552-558, 608-686), when the scene is within
+ * the reference's limits.  info[0] = 1 if available, [1] = node count, [2] = deepest level, [3] = analytic planes
+ * at the front of the primitive list.  nodes: info[1] * 16 words: AABB::sizePlusCenter.xyz,
+ * negSizePlusCenter.xyz, minPoint.xyz, maxPoint.xyz as floats, then left, right, firstPrimitiveId, primitiveCount
+ * (a leaf has left = right = 0).  order: the reference's re-ordered primitive list, ntri + nprim entries: loader
+ * triangle id, or ntri + k for analytic primitive k.  Any pointer may be NULL. */
+int rt_flat_get_ref_tree(const rt_flat *f, uint32_t info[4], uint32_t *nodes, uint32_t *order);
 /* Quality of the main tree: the rt_scene_stats counter of splits the height bound overrode, and the
  * surface-area estimate of the work per random ray through the scene's bounds (expected node visits,
  * expected ray/triangle tests).  Any pointer may be NULL. */

@@ -23,6 +23,10 @@
 //     how often that happened so parity scenes can assert "never"
 //   * optional counter-keyed RNG mode (one freshly seeded minstd_rand per (pixel, sample))
 //     so that sample ranges can be split across GPUs; mode 0 is the reference stream.
+//   * analytic primitives (Plane / Ellipsoid / Box, dead code in the reference: no loader path constructs
+//     them) can be placed as BVH::build would place them -- planes partitioned to the front and tested at
+//     the root, the others in the tree under their calculateAABB boxes (main.cpp:552-558) -- or, for checking
+//     kernels that keep them outside their own tree, folded in one by one after the triangle walk.
 //
 // Build: see oracle/Makefile (g++ -O2 -ffp-contract=off -fopenmp, x86-64 baseline = SSE2,
 // no FMA, matching the reference's Release flags: CMakeLists.txt:4, build.sh:3).
@@ -133,6 +137,22 @@ struct AABB {  // main.cpp:113-197
         minPoint = vmin(minPoint, o.minPoint);
         maxPoint = vmax(maxPoint, o.maxPoint);
     }
+    template <class Q>
+    void rotateAndTranslate(const Q &rotation, vec3 translation) {  // main.cpp:149-166
+        AABB zero = *this;
+        minPoint = V(INF, INF, INF);
+        maxPoint = V(-INF, -INF, -INF);
+        extend(rotation * zero.maxPoint);
+        extend(rotation * V(zero.maxPoint.x, zero.maxPoint.y, zero.minPoint.z));
+        extend(rotation * V(zero.maxPoint.x, zero.minPoint.y, zero.maxPoint.z));
+        extend(rotation * V(zero.minPoint.x, zero.maxPoint.y, zero.maxPoint.z));
+        extend(rotation * V(zero.maxPoint.x, zero.minPoint.y, zero.minPoint.z));
+        extend(rotation * V(zero.minPoint.x, zero.maxPoint.y, zero.minPoint.z));
+        extend(rotation * V(zero.minPoint.x, zero.minPoint.y, zero.maxPoint.z));
+        extend(rotation * zero.minPoint);
+        minPoint = minPoint + translation;
+        maxPoint = maxPoint + translation;
+    }
     void calculateEverything() {  // main.cpp:168-178  (slabs are centre +- FULL size)
         center = V((maxPoint.x + minPoint.x) / 2.f, (maxPoint.y + minPoint.y) / 2.f,
                    (maxPoint.z + minPoint.z) / 2.f);
@@ -162,7 +182,7 @@ struct Intersection {  // main.cpp:70-96
     vec3 normal{0.f, 0.f, 0.f};
     vec3 pPlusNormalEps{0.f, 0.f, 0.f};
     vec3 pMinusNormalEps{0.f, 0.f, 0.f};
-    int32_t primitive = -1;  // index into Scene::tris (build order); reference keeps a pointer
+    int32_t primitive = -1;  // loader-order triangle id, or -2 - k for analytic primitive k; reference keeps a pointer
 
     void update(vec3 o, vec3 newD, int32_t prim) {  // main.cpp:84-95
         if (!isIntersected) return;
@@ -270,11 +290,24 @@ struct Analytic {
     vec3 rotatedNormal{0.f, 0.f, 1.f};  // Plane::update, main.cpp:274-276
     vec3 radiusSq{1.f, 1.f, 1.f};       // Ellipsoid: radius squared (the reference leaves setting it to its loader)
     uint32_t material = 0;
+    AABB aabb;  // Ellipsoid / Box::calculateAABB; a plane has none (it is tested at the root, main.cpp:552-558)
 
     void update() {
         conjRotation = quat{-rotation.x, -rotation.y, -rotation.z, rotation.w};
         rotatedNormal = rotation * param;
         radiusSq = param * param;
+        aabb = AABB{};
+        if (type == PRIM_ELLIPSOID) {  // main.cpp:358-364
+            aabb.extend(param);
+            aabb.extend(-param);
+        } else if (type == PRIM_BOX) {  // main.cpp:457-463: half of the extent intersectPrimitive uses
+            aabb.extend(param / 2.f);
+            aabb.extend(-param / 2.f);
+        }
+        if (type != PRIM_PLANE) {
+            aabb.rotateAndTranslate(rotation, position);
+            aabb.calculateEverything();
+        }
     }
 
     Intersection intersectPrimitive(vec3 o, vec3 d, int32_t self) const {
@@ -364,16 +397,30 @@ struct Camera {  // main.cpp:696-700
     float fovTanX, fovTanY;
 };
 
+// One entry of InputData::primitives (main.cpp:702): the build sorts these, the triangles and analytic
+// primitives themselves stay where the loader put them.
+struct Item {
+    AABB aabb;
+    int32_t prim;  // loader-order triangle id, or -2 - k for analytic primitive k
+    bool isPlane;
+};
+
 struct Scene {  // main.cpp:689-706 (InputData), minus width/height/samples which are call arguments
-    std::vector<Triangle> tris;    // re-ordered by the build, like InputData::primitives
-    std::vector<int32_t> lights;   // indices into tris, in emission order (main.cpp:1096-1098)
+    std::vector<Triangle> tris;    // loader order
+    std::vector<int32_t> lights;   // loader-order ids of the emissive triangles, in emission order (main.cpp:1096-1098)
     std::vector<Material> mats;
     std::vector<Analytic> prims;   // Intersection::primitive of analytic primitive k is -2 - k
+    bool primsInTree = false;      // analytic primitives placed by BVH::build (true) or folded in after the walk
+    std::vector<Item> items;       // InputData::primitives: re-ordered by the build
     std::vector<BVHNode> nodes;
     Camera cam;
     // material of whatever an Intersection names
     const Material &materialOf(int32_t primitive) const {
         return mats[primitive >= 0 ? tris[primitive].material : prims[-2 - primitive].material];
+    }
+    Intersection intersectItem(const Item &it, vec3 o, vec3 d) const {
+        return it.prim >= 0 ? tris[it.prim].intersectPrimitive(o, d, it.prim)
+                            : prims[-2 - it.prim].intersectPrimitive(o, d, it.prim);
     }
     vec3 backgroundColor{0.f, 0.f, 0.f};  // never set by the loader (main.cpp:694)
     uint64_t unsplittable_nodes = 0;
@@ -382,12 +429,11 @@ struct Scene {  // main.cpp:689-706 (InputData), minus width/height/samples whic
 
 // ---------------------------------------------------------------------------------------
 // BVH build: main.cpp:552-558 and 608-686 (full-sweep SAH over 3 axes, leaf <= 4).
-// `order` plays the role of the primitives vector: it is sorted in place, range by range.
 // ---------------------------------------------------------------------------------------
 struct Builder {
     Scene &s;
-    std::vector<Triangle> &prims;  // sorted in place, like the reference's shared_ptr vector
-    explicit Builder(Scene &sc) : s(sc), prims(sc.tris) {}
+    std::vector<Item> &prims;  // sorted in place, like the reference's shared_ptr vector
+    explicit Builder(Scene &sc) : s(sc), prims(sc.items) {}
 
     void buildRecursive(size_t begin, size_t end, uint32_t depth) {
         uint32_t curNode = (uint32_t)s.nodes.size();
@@ -409,7 +455,7 @@ struct Builder {
 
         for (uint8_t division = 0; division < 3; ++division) {  // main.cpp:627-663
             std::sort(prims.begin() + begin, prims.begin() + end,
-                      [division](const Triangle &p1, const Triangle &p2) {
+                      [division](const Item &p1, const Item &p2) {
                           if (division == 0) return p1.aabb.center.x < p2.aabb.center.x;
                           if (division == 1) return p1.aabb.center.y < p2.aabb.center.y;
                           return p1.aabb.center.z < p2.aabb.center.z;
@@ -440,7 +486,7 @@ struct Builder {
 
         const uint8_t div = s.nodes[curNode].division;  // main.cpp:665-673
         std::sort(prims.begin() + begin, prims.begin() + end,
-                  [div](const Triangle &p1, const Triangle &p2) {
+                  [div](const Item &p1, const Item &p2) {
                       if (div == 0) return p1.aabb.center.x < p2.aabb.center.x;
                       if (div == 1) return p1.aabb.center.y < p2.aabb.center.y;
                       return p1.aabb.center.z < p2.aabb.center.z;
@@ -459,6 +505,26 @@ struct Builder {
         buildRecursive(middle, end, depth + 1);
     }
 };
+
+// BVH::build, main.cpp:552-558: InputData::primitives = the triangles in loader order, then (when they are
+// placed in the tree) the analytic primitives in list order; planes are partitioned to the front and the
+// root's range is widened over them.
+void buildScene(Scene &s) {
+    s.items.clear();
+    s.nodes.clear();
+    s.unsplittable_nodes = 0;
+    s.max_depth_seen = 0;
+    for (size_t i = 0; i < s.tris.size(); ++i) s.items.push_back(Item{s.tris[i].aabb, (int32_t)i, false});
+    if (s.primsInTree)
+        for (size_t k = 0; k < s.prims.size(); ++k)
+            s.items.push_back(Item{s.prims[k].aabb, -2 - (int32_t)k, s.prims[k].type == PRIM_PLANE});
+    auto begin = std::partition(s.items.begin(), s.items.end(), [](const Item &it) { return it.isPlane; });
+    const size_t nplanes = (size_t)std::distance(s.items.begin(), begin);
+    Builder b(s);
+    b.buildRecursive(nplanes, s.items.size(), 0);
+    s.nodes[0].firstPrimitiveId = 0;
+    s.nodes[0].primitiveCount += (uint32_t)nplanes;
+}
 
 // main.cpp:560-605.  Root is node 0; leaves have left = right = 0 and are filtered by
 // "!= root".  main.cpp:582-584 swaps the two child distances with
@@ -479,7 +545,7 @@ Intersection bvhIntersectRef(const Scene &s, vec3 o, vec3 d, uint32_t curNode, f
     ++c.nodes;
     for (uint32_t i = node.firstPrimitiveId; i < node.firstPrimitiveId + node.primitiveCount; ++i) {
         ++c.tri_tests;
-        Intersection ni = s.tris[i].intersectPrimitive(o, d, (int32_t)i);
+        Intersection ni = s.intersectItem(s.items[i], o, d);
         if (ni.isIntersected && closest.isIntersected && ni.t == closest.t) {
             tie = true;
             tie_t = ni.t;
@@ -524,11 +590,11 @@ Intersection bvhIntersectRef(const Scene &s, vec3 o, vec3 d, uint32_t curNode, f
     return closest;
 }
 
-// Analytic primitives are tested one by one (the reference tests its planes at the root of the walk,
-// main.cpp:552-558, 564-570; its boxes' tree boxes are half the size its intersection uses, 374-375 vs
-// 459-460, so walking them through a tree would lose hits).  Strict minimum, list order, and like a
-// triangle's a hit needs t < INF.
+// Analytic primitives kept outside the tree (Scene::primsInTree false: not the reference's structure, but that
+// of kernels that walk a triangle-only tree of their own): tested one by one after the walk.  Strict minimum,
+// list order, and like a triangle's a hit needs t < INF.
 inline void foldAnalytic(const Scene &s, vec3 o, vec3 d, Intersection &closest) {
+    if (s.primsInTree) return;
     for (size_t k = 0; k < s.prims.size(); ++k) {
         Intersection ni = s.prims[k].intersectPrimitive(o, d, -2 - (int32_t)k);
         if (ni.isIntersected && ni.t < INF && (!closest.isIntersected || ni.t < closest.t)) closest = ni;
@@ -745,23 +811,45 @@ void *orc_scene_create(const float *tri_verts, const uint32_t *tri_material, uin
         // main.cpp:1096-1098
         if (length(s->mats[t.material].emission) > EPS) isLight[i] = 1;
     }
-    // main.cpp:552-558: no planes exist (only Triangle is ever constructed, main.cpp:1089),
-    // so the partition is the identity and the root keeps its own range.
-    if (ntri > 0) {
-        Builder b(*s);
-        b.buildRecursive(0, ntri, 0);
-    } else {
-        s->nodes.push_back(BVHNode{});
-    }
     // lights keep the loader's order; the reference stores raw pointers that survive the sort.
-    std::vector<int32_t> posOfOrig(ntri);
-    for (uint32_t i = 0; i < ntri; ++i) posOfOrig[s->tris[i].origId] = (int32_t)i;
     for (uint32_t i = 0; i < ntri; ++i)
-        if (isLight[i]) s->lights.push_back(posOfOrig[i]);
+        if (isLight[i]) s->lights.push_back((int32_t)i);
+    // main.cpp:552-558 (no planes exist so far: the loader only constructs triangles, main.cpp:1089)
+    buildScene(*s);
     return s;
 }
 
 void orc_scene_destroy(void *h) { delete asScene(h); }
+
+// The tree of BVH::build for checking another builder of the same tree against it.  nodes4: per node left,
+// right, firstPrimitiveId, primitiveCount; boxes12: per node sizePlusCenter, negSizePlusCenter, minPoint,
+// maxPoint; items: the re-ordered primitive list (loader-order triangle id, or ntri + k for analytic
+// primitive k).  Any pointer may be null.  Returns the node count.
+uint32_t orc_scene_tree(void *h, uint32_t *nodes4, float *boxes12, uint32_t *items) {
+    Scene *s = asScene(h);
+    for (size_t k = 0; k < s->nodes.size(); ++k) {
+        const BVHNode &n = s->nodes[k];
+        if (nodes4) {
+            nodes4[4 * k] = n.left;
+            nodes4[4 * k + 1] = n.right;
+            nodes4[4 * k + 2] = n.firstPrimitiveId;
+            nodes4[4 * k + 3] = n.primitiveCount;
+        }
+        if (boxes12) {
+            const vec3 v[4] = {n.aabb.sizePlusCenter, n.aabb.negSizePlusCenter, n.aabb.minPoint, n.aabb.maxPoint};
+            for (int j = 0; j < 4; ++j) {
+                boxes12[12 * k + 3 * j] = v[j].x;
+                boxes12[12 * k + 3 * j + 1] = v[j].y;
+                boxes12[12 * k + 3 * j + 2] = v[j].z;
+            }
+        }
+    }
+    if (items)
+        for (size_t i = 0; i < s->items.size(); ++i)
+            items[i] = s->items[i].prim >= 0 ? (uint32_t)s->items[i].prim
+                                             : (uint32_t)s->tris.size() + (uint32_t)(-2 - s->items[i].prim);
+    return (uint32_t)s->nodes.size();
+}
 
 // info[0]=node count, [1]=light count, [2]=unsplittable nodes (deviation counter), [3]=max depth
 void orc_scene_info(void *h, uint64_t *info) {
@@ -792,9 +880,9 @@ void orc_intersect_rays(void *h, uint64_t n, const float *o, const float *d, uin
             ++c.segments;
             if (use_bvh) {
                 it = bvhIntersectRef(*s, ro, rd, 0, INF, c, tf, tt);
-            } else {  // brute force over all triangles in build order
-                for (uint32_t k = 0; k < s->tris.size(); ++k) {
-                    Intersection ni = s->tris[k].intersectPrimitive(ro, rd, (int32_t)k);
+            } else {  // brute force over all primitives in build order
+                for (size_t k = 0; k < s->items.size(); ++k) {
+                    Intersection ni = s->intersectItem(s->items[k], ro, rd);
                     if (ni.isIntersected && it.isIntersected && ni.t == it.t) {
                         tf = true;
                         tt = ni.t;
@@ -804,7 +892,7 @@ void orc_intersect_rays(void *h, uint64_t n, const float *o, const float *d, uin
             }
             foldAnalytic(*s, ro, rd, it);
             prim_id[i] = !it.isIntersected ? 0xFFFFFFFFu
-                         : it.primitive >= 0 ? s->tris[it.primitive].origId
+                         : it.primitive >= 0 ? (uint32_t)it.primitive
                                              : (uint32_t)s->tris.size() + (uint32_t)(-2 - it.primitive);
             t[i] = it.t;
             if (tie) tie[i] = (tf && it.isIntersected && tt == it.t) ? 1 : 0;
@@ -917,7 +1005,8 @@ void orc_tonemap(const float *radiance_sum, uint64_t npixels, uint32_t spp, floa
 void orc_scene_set_background(void *h, float r, float g, float b) { asScene(h)->backgroundColor = V(r, g, b); }
 
 // Analytic primitives: n records of {int32 type; float position[3]; float rotation[4] (x, y, z, w);
-// float param[3]; uint32 material}.
+// float param[3]; uint32 material}.  in_tree != 0: they join InputData::primitives behind the triangles and
+// BVH::build places them (main.cpp:552-558); in_tree == 0: they are folded in after the walk (foldAnalytic).
 struct orc_primitive {
     int32_t type;
     float position[3];
@@ -925,7 +1014,7 @@ struct orc_primitive {
     float param[3];
     uint32_t material;
 };
-void orc_scene_set_primitives(void *h, const orc_primitive *p, uint32_t n) {
+void orc_scene_set_primitives(void *h, const orc_primitive *p, uint32_t n, int in_tree) {
     Scene *s = asScene(h);
     s->prims.resize(n);
     for (uint32_t k = 0; k < n; ++k) {
@@ -937,6 +1026,8 @@ void orc_scene_set_primitives(void *h, const orc_primitive *p, uint32_t n) {
         a.material = p[k].material;
         a.update();
     }
+    s->primsInTree = in_tree != 0;
+    buildScene(*s);
 }
 
 // Known-answer probe of the RNG layer (main.cpp:98-111), each group from a freshly seeded engine.
@@ -1004,7 +1095,7 @@ void orc_triangle_derived(void *h, float *out4) {
 uint32_t orc_lights(void *h, uint32_t *out, uint32_t cap) {
     Scene *s = asScene(h);
     uint32_t n = (uint32_t)s->lights.size();
-    for (uint32_t i = 0; i < n && i < cap; ++i) out[i] = s->tris[s->lights[i]].origId;
+    for (uint32_t i = 0; i < n && i < cap; ++i) out[i] = (uint32_t)s->lights[i];
     return n;
 }
 

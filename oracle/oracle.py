@@ -54,8 +54,10 @@ def lib():
                                        C.POINTER(Camera)]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_scene_set_background.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
-        L.orc_scene_set_primitives.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_scene_set_primitives.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
         L.orc_scene_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_scene_tree.restype = C.c_uint32
+        L.orc_scene_tree.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_intersect_rays.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_primary_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -90,7 +92,9 @@ class OracleScene:
     camera: dict(position, right, up, forward, tan_x, tan_y).
     """
 
-    def __init__(self, tri_verts, tri_material, materials, camera, background=None, prims=None):
+    def __init__(self, tri_verts, tri_material, materials, camera, background=None, prims=None, prims_in_tree=False):
+        """prims_in_tree: analytic primitives are placed as BVH::build would place them (planes at the root, the
+        others in the tree under their own boxes, main.cpp:552-558) instead of being folded in after the walk."""
         tv = np.ascontiguousarray(tri_verts, dtype=np.float32).reshape(-1, 9)
         tm = np.ascontiguousarray(tri_material, dtype=np.uint32)
         mats = np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE)
@@ -101,12 +105,14 @@ class OracleScene:
         cam.tan_x = float(camera["tan_x"])
         cam.tan_y = float(camera["tan_y"])
         self.ntri = tv.shape[0]
+        self.nprims = 0 if prims is None else len(prims)
+        self.prims_in_tree = bool(prims_in_tree) and self.nprims > 0
         self._h = lib().orc_scene_create(_p(tv), _p(tm), self.ntri, _p(mats), mats.shape[0], C.byref(cam))
         if background is not None:
             lib().orc_scene_set_background(self._h, *[float(x) for x in background])
         if prims is not None and len(prims):
             pr = np.ascontiguousarray(prims, dtype=PRIMITIVE_DTYPE)
-            lib().orc_scene_set_primitives(self._h, _p(pr), pr.shape[0])
+            lib().orc_scene_set_primitives(self._h, _p(pr), pr.shape[0], int(bool(prims_in_tree)))
 
     def close(self):
         if self._h:
@@ -123,6 +129,16 @@ class OracleScene:
         out = np.zeros(4, dtype=np.uint64)
         lib().orc_scene_info(self._h, _p(out))
         return dict(nodes=int(out[0]), lights=int(out[1]), unsplittable=int(out[2]), max_depth=int(out[3]))
+
+    def tree(self):
+        """BVH::build's result: (nodes (n, 4) u32: left, right, first, count; boxes (n, 12) f32: sizePlusCenter,
+        negSizePlusCenter, minPoint, maxPoint; items: the re-ordered primitive list as loader ids)."""
+        n = lib().orc_scene_tree(self._h, None, None, None)
+        nodes = np.empty((n, 4), dtype=np.uint32)
+        boxes = np.empty((n, 12), dtype=np.float32)
+        items = np.empty(max(self.ntri + self.nprims, 1), dtype=np.uint32)
+        lib().orc_scene_tree(self._h, _p(nodes), _p(boxes), _p(items))
+        return nodes, boxes, items[:self.ntri + self.nprims if self.prims_in_tree else self.ntri]
 
     def intersect(self, o, d, use_bvh=True):
         o = np.ascontiguousarray(o, dtype=np.float32).reshape(-1, 3)

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "lib", "librt_amd
 RT_OK = 0
 RNG_REFERENCE, RNG_COUNTER = 0, 1
 PIPE_MEGAKERNEL, PIPE_WAVEFRONT = 0, 1
+HITS_LEAF_ORDER, HITS_REFERENCE_ORDER, HITS_REFERENCE_WALK = 0, 1, 2
 MISS_ID = 0xFFFFFFFF
 INF = 10000.0
 
@@ -36,7 +37,8 @@ class SceneDesc(C.Structure):
 class SceneStats(C.Structure):
     _fields_ = [("ntri", C.c_uint32), ("nlights", C.c_uint32), ("nnodes", C.c_uint32), ("tree_height", C.c_uint32),
                 ("build_seconds", C.c_double), ("device_bytes", C.c_uint64), ("height_capped_splits", C.c_uint32),
-                ("nprims", C.c_uint32), ("ntri_records", C.c_uint32)]
+                ("nprims", C.c_uint32), ("ntri_records", C.c_uint32), ("hit_order", C.c_uint32),
+                ("ref_tree_nodes", C.c_uint32), ("ref_tree_depth", C.c_uint32)]
 
 
 class Counters(C.Structure):
@@ -62,6 +64,8 @@ SIGNATURES = {
     "rt_scene_create": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]),
     "rt_scene_destroy": (None, [C.c_void_p]),
     "rt_scene_get_stats": (C.c_int, [C.c_void_p, C.POINTER(SceneStats)]),
+    "rt_scene_set_hit_order": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_flat_get_ref_tree": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_scene_get_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_flat_build": (C.c_int, [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]),
     "rt_flat_get_light_tree": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -12,7 +12,8 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (PIPE_MEGAKERNEL, PIPE_WAVEFRONT, RNG_COUNTER, RNG_REFERENCE, MISS_ID, INF, RtError, check)
+from ._lib import (PIPE_MEGAKERNEL, PIPE_WAVEFRONT, RNG_COUNTER, RNG_REFERENCE, HITS_LEAF_ORDER, HITS_REFERENCE_ORDER, HITS_REFERENCE_WALK,
+                   MISS_ID, INF, RtError, check)
 
 MATERIAL_DTYPE = np.dtype([("color", "<f4", 3), ("emission", "<f4", 3), ("type", "<i4"), ("ior", "<f4")])
 # rt_primitive: Plane / Ellipsoid / Box of main.cpp:242-464 (type 0 / 1 / 2; rotation = unit quaternion x, y, z, w;
@@ -133,6 +134,15 @@ def build_flat(host_scene):
         check(L.rt_flat_get_light_tree(h, None, _p(lgrid), _p(lnodes), _p(lrecs) if lights.size else None))
         capped, sah_n, sah_t = C.c_uint32(), C.c_double(), C.c_double()
         check(L.rt_flat_get_quality(h, C.byref(capped), C.byref(sah_n), C.byref(sah_t)))
+        rinfo = np.zeros(4, dtype=np.uint32)
+        check(L.rt_flat_get_ref_tree(h, _p(rinfo), None, None))
+        ref_tree = None
+        if rinfo[0]:
+            rnodes = np.empty((int(rinfo[1]), 16), dtype=np.uint32)
+            rorder = np.empty(max(host_scene.tri_material.shape[0] + host_scene.prims.shape[0], 1), dtype=np.uint32)
+            check(L.rt_flat_get_ref_tree(h, None, _p(rnodes), _p(rorder)))
+            ref_tree = dict(nodes=rnodes, order=rorder[:host_scene.tri_material.shape[0] + host_scene.prims.shape[0]],
+                            depth=int(rinfo[2]), nplanes=int(rinfo[3]))
         nwide = C.c_uint32()
         check(L.rt_flat_get_wide(h, C.byref(nwide), None))
         wide = np.empty((int(nwide.value), 12), dtype=np.uint32)
@@ -141,7 +151,7 @@ def build_flat(host_scene):
         L.rt_flat_free(h)
     return dict(nodes=nodes, wide=wide, grid=grid, tris=tris, lights=lights, height=int(info[3]),
                 height_capped_splits=int(capped.value), sah_nodes=float(sah_n.value), sah_tris=float(sah_t.value),
-                light_tree=dict(nodes=lnodes, grid=lgrid, recs=lrecs, height=int(linfo[1])))
+                light_tree=dict(nodes=lnodes, grid=lgrid, recs=lrecs, height=int(linfo[1])), ref_tree=ref_tree)
 
 
 class Scene:
@@ -179,7 +189,14 @@ class Scene:
         check(_lib.lib().rt_scene_get_stats(self._h, C.byref(s)))
         return dict(ntri=s.ntri, nlights=s.nlights, nnodes=s.nnodes, tree_height=s.tree_height,
                     build_seconds=s.build_seconds, device_bytes=int(s.device_bytes),
-                    height_capped_splits=s.height_capped_splits, nprims=s.nprims, ntri_records=s.ntri_records)
+                    height_capped_splits=s.height_capped_splits, nprims=s.nprims, ntri_records=s.ntri_records,
+                    hit_order=s.hit_order, ref_tree_nodes=s.ref_tree_nodes, ref_tree_depth=s.ref_tree_depth)
+
+    def set_hit_order(self, order):
+        """HITS_REFERENCE_ORDER: results that depend on the reference's traversal order (equal distances above
+        all) are resolved as the reference resolves them; HITS_LEAF_ORDER: the kernels' own rule.  Raises
+        RtError (RT_ERR_LIMIT) when the scene is beyond what the reference itself can hold."""
+        check(_lib.lib().rt_scene_set_hit_order(self._h, int(order)))
 
     def flat(self):
         st = self.stats()

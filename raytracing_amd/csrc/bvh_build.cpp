@@ -614,6 +614,8 @@ void build_flat_scene(const rt_scene_desc &desc, FlatScene &out) {
         q[13] = bits_to_float(out.lights[li]);
     }
     if (nl == 0) out.light_recs[0] = out.light_recs[1] = out.light_recs[2] = 3.0e30f;  // never hit
+    // The reference's own tree, for the kernels that resolve order-dependent hits as it does (scenes within its limits)
+    build_ref_tree(desc, posOfId, nslots, out.ref);
     out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
@@ -695,6 +697,27 @@ int rt_flat_get_wide(const rt_flat *f, uint32_t *nwide, uint32_t *nodes) {
     }
     if (nwide) *nwide = f->flat.nwide;
     if (nodes) std::memcpy(nodes, f->flat.wide.data(), f->flat.wide.size() * sizeof(uint32_t));
+    return RT_OK;
+}
+
+int rt_flat_get_ref_tree(const rt_flat *f, uint32_t info[4], uint32_t *nodes, uint32_t *order) {
+    if (!f) {
+        rt::set_error("rt_flat_get_ref_tree: null argument");
+        return RT_ERR_INVALID;
+    }
+    const rt::RefTree &r = f->flat.ref;
+    if (info) {
+        info[0] = r.available ? 1u : 0u;
+        info[1] = r.available ? r.nnodes : 0u;
+        info[2] = r.available ? r.depth : 0u;
+        info[3] = r.available ? r.nplanes : 0u;
+    }
+    if (!r.available) {
+        rt::set_error("rt_flat_get_ref_tree: " + r.reason);
+        return (nodes || order) ? RT_ERR_LIMIT : RT_OK;
+    }
+    if (nodes) std::memcpy(nodes, r.nodes.data(), r.nodes.size() * sizeof(uint32_t));
+    if (order && !r.order.empty()) std::memcpy(order, r.order.data(), r.order.size() * sizeof(uint32_t));
     return RT_OK;
 }
 

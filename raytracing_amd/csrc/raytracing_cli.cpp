@@ -16,6 +16,9 @@
 //     --gltf-spec      read the scene by the glTF 2.0 rules the reference does not follow (RT_GLTF_SPEC:
 //                      byteStride, index offsets, data URIs, node hierarchy, .glb, KHR_materials_ior)
 //     --gltf-background  take the background colour from scenes[scene].extras.backgroundColor
+//     --hit-order O    leaf | reference | walk: how hits that depend on the reference's traversal order (equal
+//                      distances above all) are resolved (RT_HITS_*; default: reference for scenes the reference
+//                      itself can hold, leaf beyond)
 // All rendering runs on the GPU through the C ABI of librt_amd.so; there is no CPU fallback.
 #include <chrono>
 #include <cstdio>
@@ -40,7 +43,8 @@ int main(int argc, char *argv[]) {
     if (argc < 6) {
         std::fprintf(stderr,
                      "usage: %s <scene.gltf> <width> <height> <samples> <output.ppm> [--depth N] [--rng reference|counter]"
-                     " [--pipeline mega|wavefront] [--seed S] [--device D] [--gpus N] [--dump-hits FILE] [--gltf-spec] [--gltf-background]\n",
+                     " [--pipeline mega|wavefront] [--seed S] [--device D] [--gpus N] [--dump-hits FILE] [--gltf-spec] [--gltf-background]"
+                     " [--hit-order leaf|reference|walk]\n",
                      argv[0]);
         return 2;
     }
@@ -51,7 +55,7 @@ int main(int argc, char *argv[]) {
         return 2;
     }
     uint32_t depth = 6, seed = 0, gltfFlags = 0;
-    int rng = RT_RNG_REFERENCE, pipeline = RT_PIPE_MEGAKERNEL, device = 0, gpus = 0;
+    int rng = RT_RNG_REFERENCE, pipeline = RT_PIPE_MEGAKERNEL, device = 0, gpus = 0, hitOrder = -1;
     std::string dumpHits;
     for (int i = 6; i < argc; ++i) {
         std::string a = argv[i];
@@ -75,6 +79,15 @@ int main(int argc, char *argv[]) {
             else if (v == "counter") rng = RT_RNG_COUNTER;
             else {
                 std::fprintf(stderr, "raytracing: --rng must be reference or counter\n");
+                return 2;
+            }
+        } else if (a == "--hit-order") {
+            std::string v = need("--hit-order");
+            if (v == "leaf") hitOrder = RT_HITS_LEAF_ORDER;
+            else if (v == "reference") hitOrder = RT_HITS_REFERENCE_ORDER;
+            else if (v == "walk") hitOrder = RT_HITS_REFERENCE_WALK;
+            else {
+                std::fprintf(stderr, "raytracing: --hit-order must be leaf, reference or walk\n");
                 return 2;
             }
         } else if (a == "--pipeline") {
@@ -109,6 +122,9 @@ int main(int argc, char *argv[]) {
         return die("uploading the scene");
     }
     rt_host_scene_free(hs);
+    if (hitOrder >= 0)
+        for (int g = 0; g < (multi ? rt_multi_device_count(multi) : 1); ++g)
+            if (rt_scene_set_hit_order(multi ? rt_multi_scene(multi, g) : scene, hitOrder) != RT_OK) return die("--hit-order");
     std::printf("Processed input after %gs\n", now() - start);
 
     const size_t npix = (size_t)width * height;

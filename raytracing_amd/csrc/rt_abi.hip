@@ -190,6 +190,7 @@ int ensure_wavefront(rt_scene *s, uint32_t npix, uint32_t slots) {
     w.sort = s->sort_rays;
     w.sort_min_rays = s->sort_min_rays;
     w.wide = s->wide_tree;
+    w.ties = s->hit_order != RT_HITS_LEAF_ORDER;
     w.stack_limit = s->stack_limit;
     return RT_OK;
 }
@@ -308,6 +309,12 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
     RT_TRY(dev_alloc(s, &s->d_mats, mats.size()));
     RT_TRY(dev_alloc(s, &s->d_prims, f.prims.size() / 4));
     RT_TRY(hipMemcpy(s->d_prims, f.prims.data(), f.prims.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (f.ref.available) {
+        RT_TRY(dev_alloc(s, &s->d_rnodes, f.ref.nodes.size() / 4));
+        RT_TRY(hipMemcpy(s->d_rnodes, f.ref.nodes.data(), f.ref.nodes.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        RT_TRY(dev_alloc(s, &s->d_ritems, f.ref.items.size()));
+        RT_TRY(hipMemcpy(s->d_ritems, f.ref.items.data(), f.ref.items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     RT_TRY(dev_alloc(s, &s->d_counters, kCounterWords));
     RT_TRY(hipMemcpy(s->d_nodes, f.nodes.data(), f.nodes.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     RT_TRY(hipMemcpy(s->d_tris, f.tris.data(), f.tris.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -338,6 +345,16 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
     }
     v.mats = s->d_mats;
     v.prims = s->d_prims;
+    v.rnodes = s->d_rnodes;
+    v.ritems = s->d_ritems;
+    {
+        // Results that depend on the reference's traversal order (equal distances above all: coincident faces, a
+        // box standing on a floor) are resolved as the reference resolves them whenever the scene is one the
+        // reference itself can hold; RT_HIT_ORDER=leaf keeps the kernels' own rule (rt_scene_set_hit_order).
+        s->hit_order = f.ref.available ? RT_HITS_REFERENCE_ORDER : RT_HITS_LEAF_ORDER;
+        if (const char *e = std::getenv("RT_HIT_ORDER"))
+            if (std::strcmp(e, "leaf") == 0) s->hit_order = RT_HITS_LEAF_ORDER;
+    }
     v.ntri = f.nslots;
     v.npad = f.nslots - f.ntri;
     v.nprims = f.nprims;
@@ -407,6 +424,8 @@ void rt_scene_destroy(rt_scene *s) {
     (void)hipFree(s->d_lrecs);
     (void)hipFree(s->d_mats);
     (void)hipFree(s->d_prims);
+    (void)hipFree(s->d_rnodes);
+    (void)hipFree(s->d_ritems);
     (void)hipFree(s->d_counters);
     delete s;
 }
@@ -422,6 +441,21 @@ int rt_scene_get_stats(const rt_scene *s, rt_scene_stats *out) {
     out->device_bytes = s->device_bytes;
     out->height_capped_splits = s->flat->capped_splits;
     out->nprims = s->flat->nprims;
+    out->hit_order = (uint32_t)s->hit_order;
+    out->ref_tree_nodes = s->flat->ref.available ? s->flat->ref.nnodes : 0u;
+    out->ref_tree_depth = s->flat->ref.available ? s->flat->ref.depth : 0u;
+    return RT_OK;
+}
+
+int rt_scene_set_hit_order(rt_scene *s, int order) {
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_set_hit_order: null scene");
+    if (order != RT_HITS_LEAF_ORDER && order != RT_HITS_REFERENCE_ORDER && order != RT_HITS_REFERENCE_WALK)
+        return fail(RT_ERR_INVALID, "rt_scene_set_hit_order: order must be one of RT_HITS_*");
+    if (order != RT_HITS_LEAF_ORDER && !s->flat->ref.available)
+        return fail(RT_ERR_LIMIT, "rt_scene_set_hit_order: the reference's own tree is not available for this scene: " +
+                                      s->flat->ref.reason);
+    s->hit_order = order;
+    s->wf.ties = order != RT_HITS_LEAF_ORDER;
     return RT_OK;
 }
 
@@ -444,7 +478,8 @@ int rt_intersect_rays_dev(rt_scene *s, uint64_t n, const float *d_origins, const
     if (!d_origins || !d_directions || !d_prim_id || !d_t) return fail(RT_ERR_INVALID, "rt_intersect_rays_dev: null buffer");
     if (n > (1ull << 31)) return fail(RT_ERR_LIMIT, "rt_intersect_rays_dev: more than 2^31 rays in one call");
     DeviceGuard g(s->device);
-    RT_HIP(rt::launch_intersect(s->view, n, d_origins, d_directions, d_prim_id, d_t, s->counting, (hipStream_t)stream, s->timer));
+    RT_HIP(rt::launch_intersect(s->view, n, d_origins, d_directions, d_prim_id, d_t, s->counting,
+                                s->hit_order != RT_HITS_LEAF_ORDER, (hipStream_t)stream, s->timer));
     s->host_segments += n;
     return RT_OK;
 }
@@ -481,7 +516,8 @@ int rt_trace_primary_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t 
     int rc = check_image(width, height);
     if (rc != RT_OK) return rc;
     DeviceGuard g(s->device);
-    RT_HIP(rt::launch_primary(s->view, width, height, d_prim_id, d_t, s->counting, (hipStream_t)stream, s->timer));
+    RT_HIP(rt::launch_primary(s->view, width, height, d_prim_id, d_t, s->counting, s->hit_order != RT_HITS_LEAF_ORDER,
+                              (hipStream_t)stream, s->timer));
     s->host_segments += (uint64_t)width * height;
     return RT_OK;
 }
@@ -522,18 +558,23 @@ int rt_render_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_beg
     if ((uint64_t)spp_begin + spp_count > 0xFFFFFFFFull) return fail(RT_ERR_LIMIT, "rt_render_dev: sample range overflows 32 bits");
     DeviceGuard g(s->device);
     rt::RenderParams rp{width, height, spp_begin, spp_count, max_depth, rng_mode, seed};
+    const bool ref_order = s->hit_order != RT_HITS_LEAF_ORDER;
     if (pipeline == RT_PIPE_MEGAKERNEL && rng_mode == RT_RNG_REFERENCE) {
         // the reference's stream in the reference's evaluation order (bit-exact validation path)
         if (max_depth > 64) return fail(RT_ERR_LIMIT, "rt_render_dev: RT_RNG_REFERENCE supports max_depth <= 64");
         rc = ensure_replay(s, rp);
         if (rc != RT_OK) return rc;
-        RT_HIP(rt::launch_render_replay(s->view, rp, d_radiance_sum, s->d_replay, s->counting, (hipStream_t)stream, s->timer));
+        RT_HIP(rt::launch_render_replay(s->view, rp, d_radiance_sum, s->d_replay, s->counting, ref_order, (hipStream_t)stream, s->timer));
     } else if (pipeline == RT_PIPE_MEGAKERNEL) {
-        RT_HIP(rt::launch_render_mega(s->view, rp, d_radiance_sum, s->counting, (hipStream_t)stream, s->timer));
+        const int order = s->hit_order == RT_HITS_REFERENCE_WALK    ? rtd::kOrderRefFull
+                          : s->hit_order == RT_HITS_REFERENCE_ORDER ? rtd::kOrderRefTies
+                                                                    : rtd::kOrderLeaf;
+        RT_HIP(rt::launch_render_mega(s->view, rp, d_radiance_sum, s->counting, order, (hipStream_t)stream, s->timer));
     } else {
         const uint32_t slots = wavefront_slots(width * height, spp_count);
         rc = ensure_wavefront(s, width * height, slots);
         if (rc != RT_OK) return rc;
+        s->wf.ties = ref_order;
         RT_HIP(rt::launch_render_wavefront(s->view, rp, d_radiance_sum, s->wf, slots, s->counting, (hipStream_t)stream, s->timer));
     }
     return RT_OK;
@@ -574,6 +615,7 @@ int rt_render_noalloc_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t
     wb.sort = s->sort_rays;
     wb.sort_min_rays = s->sort_min_rays;
     wb.wide = s->wide_tree;
+    wb.ties = s->hit_order != RT_HITS_LEAF_ORDER;
     wb.stack_limit = s->stack_limit;
     wb.qcount = reinterpret_cast<uint32_t *>(base + kScratchQcount);
     wb.cursors = reinterpret_cast<uint32_t *>(base + kScratchCursors);

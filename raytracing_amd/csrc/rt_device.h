@@ -123,6 +123,8 @@ struct DevScene {
     const uint32_t *lights;   // leaf-order positions of the emissive triangles
     const DevMaterial *mats;
     const float4 *prims;      // 3 x float4 per analytic primitive: (position.xyz, bits(type)), rotation xyzw, (param.xyz, bits(material))
+    const float4 *rnodes;     // 4 x float4 per node of the tree the reference itself would build (ref_closest_hit); null when the scene is beyond its limits
+    const uint32_t *ritems;   // the reference's re-ordered primitive list as record indices (triangle record, or ntri + k)
     unsigned long long *counters;  // kCounterShards x kCounterStride; per shard [0] segments [1] nodes [2] tri tests [3] light tests
     uint32_t nlights, nmats;
     uint32_t ntri, nprims;               // ntri = triangle RECORDS (pads included): a hit index >= ntri names analytic primitive (index - ntri)
@@ -221,7 +223,9 @@ __device__ __forceinline__ bool tri_test(float4 q0, float4 q1, float4 q2, v3 o, 
 // height bound (kStack inner levels) is what keeps the stack from overflowing.
 constexpr int kSentinel = 0x7FFFFFFF;  // "stack is empty": never a node index, never a leaf reference
 
-template <bool COUNT, int EXIT_LANES = 0, bool HELP = false, bool WIDE = false>
+// TIES: the walk only notes (in `tie`) that a second primitive came back at exactly the best distance; the
+// caller then asks ref_closest_hit, which answers in the reference's own order.
+template <bool COUNT, int EXIT_LANES = 0, bool HELP = false, bool WIDE = false, bool TIES = false>
 struct Traversal {
     struct f2 {
         float x, y;
@@ -242,6 +246,7 @@ struct Traversal {
     // again on the two-child tree
     int limit;
     bool overflow;
+    bool tie;  // TIES: the best distance so far was returned by more than one primitive
 
     // lane_stack: &lds[threadIdx.x]
     __device__ __forceinline__ void bind(int *lane_stack) { stack = lane_stack; }
@@ -280,6 +285,7 @@ struct Traversal {
         leaf = 0;
         sp = 0;
         overflow = false;
+        tie = false;
     }
     __device__ __forceinline__ void idle() {  // a lane with no ray: steps are no-ops
         cur = kSentinel;
@@ -288,9 +294,19 @@ struct Traversal {
     }
     __device__ __forceinline__ bool done() const { return cur == kSentinel && leaf == 0; }
     // Strict minimum (main.cpp:563-571).  Two triangles at exactly the same distance (a ray through a shared
-    // edge): the reference keeps whichever its own tree meets first; here the one earlier in leaf order wins,
-    // whatever tree is walked in whatever order, so that every kernel names the same triangle.
-    __device__ __forceinline__ bool closer(float t, int tri) const { return t < tBest || (t == tBest && tri < triBest); }
+    // edge, two coincident faces): the reference keeps whichever its own tree meets first.  Without TIES the one
+    // earlier in leaf order wins, whatever tree is walked in whatever order, so that every kernel names the same
+    // triangle; with TIES the event is noted and the caller has the ray traced in the reference's order.
+    __device__ __forceinline__ void consider(float t, int tri) {
+        if (t < tBest) {
+            tBest = t;
+            triBest = tri;
+            if (TIES) tie = false;
+        } else if (t == tBest) {
+            if (TIES) tie = true;
+            else if (tri < triBest) triBest = tri;
+        }
+    }
     __device__ __forceinline__ int pop() {
         if (sp == 0) return kSentinel;
         --sp;
@@ -433,10 +449,7 @@ struct Traversal {
                     const float4 *tp = S.tris + 4 * (size_t)(first + k);
                     float t;
                     if (COUNT) ++st.tris;
-                    if (tri_test(tp[0], tp[1], tp[2], o, d, t) && closer(t, (int)(first + k))) {
-                        tBest = t;
-                        triBest = (int)(first + k);
-                    }
+                    if (tri_test(tp[0], tp[1], tp[2], o, d, t)) consider(t, (int)(first + k));
                 }
                 leaf = 0;
                 if (cur < 0) {
@@ -480,23 +493,14 @@ struct Traversal {
             }
             if (has) {
                 if (COUNT) st.tris += cnt;
-                if (hit && closer(t, (int)first)) {
-                    tBest = t;
-                    triBest = (int)first;
-                }
+                if (hit) consider(t, (int)first);
                 if (lend) {
                     const float t2 = __uint_as_float(xchg[64 + drank]);  // kInf when the helper's test missed
-                    if (t2 < kInf && closer(t2, (int)first + 1)) {
-                        tBest = t2;
-                        triBest = (int)first + 1;
-                    }
+                    if (t2 < kInf) consider(t2, (int)first + 1);
                 } else if (cnt == 2u) {  // more two-triangle leaves than idle lanes: test it here
                     const float4 *tp = S.tris + 4 * (size_t)(first + 1u);
                     float t2;
-                    if (tri_test(tp[0], tp[1], tp[2], o, d, t2) && closer(t2, (int)first + 1)) {
-                        tBest = t2;
-                        triBest = (int)first + 1;
-                    }
+                    if (tri_test(tp[0], tp[1], tp[2], o, d, t2)) consider(t2, (int)first + 1);
                 }
                 leaf = 0;
                 if (cur < 0) {
@@ -608,27 +612,167 @@ __device__ __forceinline__ PrimHit prim_intersect(const float4 *rec, v3 o, v3 d)
     return h;
 }
 
-// Folds the analytic primitives into a finished triangle walk: strict minimum, in list order.
-__device__ __forceinline__ void analytic_closest(const DevScene &S, v3 o, v3 d, float &tBest, int &triBest) {
+// Folds the analytic primitives into a finished triangle walk: strict minimum, in list order.  Returns whether a
+// primitive came back at exactly the best distance (a tie the reference resolves by its own order).
+__device__ __forceinline__ bool analytic_closest(const DevScene &S, v3 o, v3 d, float &tBest, int &triBest) {
+    bool tie = false;
     for (uint32_t k = 0; k < S.nprims; ++k) {
         const PrimHit h = prim_intersect<false>(S.prims + 3 * (size_t)k, o, d);
         if (h.hit && h.t < tBest) {
             tBest = h.t;
             triBest = (int)(S.ntri + k);
+            tie = false;
+        } else if (h.hit && h.t == tBest) {
+            tie = true;
         }
     }
+    return tie;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The reference's own walk (BVH::intersect, main.cpp:560-605) over the reference's own tree (S.rnodes /
+// S.ritems, built by ref_tree.cpp): for the results that depend on the ORDER in which primitives are met.
+//   * two primitives at exactly the same distance: the first met wins (strict `<`, main.cpp:566-567, 589-590);
+//   * a ray in the plane of a triangle: the 3x3 inverse divides by zero, every comparison of main.cpp:483 fails
+//     and the "hit" at distance NaN is kept if it is the first of its leaf (566), after which nothing
+//     compares closer and no further subtree is entered (`distance < NaN`, 587, 596);
+//   * a hit at t >= INF survives if it is the first of its leaf and nothing nearer is found later;
+//   * every call starts from minDistance = its own closest hit (main.cpp:571): a subtree is cut only by its
+//     sibling's hit, and the boxes are twice their size (center +- (max - min), 174-177), origin inside -> 0.
+// The recursion is unrolled over a stack of frames, one per call that is waiting for a child: the call's
+// closest hit so far and, while the first child runs, the second child with its box distance.  A frame's
+// `right` is nonzero exactly while the first child is out (children are never the root, node 0).
+// Private memory (1 KB per lane): this is the walk of the validation paths and of the few rays the fast
+// walks hand over, not a throughput path.  The host guarantees depth <= kRefStack.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRefStack = 64;
+constexpr float kBigInf = 20000.f;  // BIG_INF, main.cpp:24
+
+// AABB::intersect, main.cpp:180-196, on a node record (sizePlusCenter, negSizePlusCenter, minPoint, maxPoint)
+__device__ __forceinline__ float ref_box_distance(const float4 *n, v3 o, v3 d) {
+    const float4 q0 = n[0], q1 = n[1], q2 = n[2];
+    const v3 spc = mk(q0.x, q0.y, q0.z), nspc = mk(q0.w, q1.x, q1.y), lo = mk(q1.z, q1.w, q2.x), hi = mk(q2.y, q2.z, q2.w);
+    if (hi.x > o.x && hi.y > o.y && hi.z > o.z && lo.x < o.x && lo.y < o.y && lo.z < o.z) return 0.f;
+    const v3 t1 = vdiv(spc - o, d), t2 = vdiv(nspc - o, d);
+    const float d1 = ref_max(ref_max(ref_min(t1.x, t2.x), ref_min(t1.y, t2.y)), ref_min(t1.z, t2.z));
+    const float d2 = ref_min(ref_min(ref_max(t1.x, t2.x), ref_max(t1.y, t2.y)), ref_max(t1.z, t2.z));
+    if (d1 > d2 || d2 < 0.f) return kBigInf;
+    return d1;
+}
+
+// tOut / recOut: distance and record index (triangle record, or S.ntri + k) of the reference's answer;
+// recOut < 0 and tOut = INF when it hits nothing.  tOut may be NaN or >= INF for a hit (see above).
 template <bool COUNT>
+__device__ __noinline__ void ref_closest_hit(const DevScene &S, v3 o, v3 d, float &tOut, int &recOut, TraceStats &st) {
+    struct Frame {
+        float rd, t;
+        int rec;
+        uint32_t right;
+    };
+    Frame fr[kRefStack];
+    int sp = 0;
+    uint32_t cur = 0;
+    float rt = kInf;  // what the call that just returned hands back
+    int rrec = -1;
+    for (;;) {
+        const float4 q3 = S.rnodes[4 * (size_t)cur + 3];
+        uint32_t left = __float_as_uint(q3.x), right = __float_as_uint(q3.y);
+        const uint32_t first = __float_as_uint(q3.z), count = __float_as_uint(q3.w);
+        if (COUNT) ++st.nodes;
+        float ct = kInf;  // closestIntersection of this call (main.cpp:562): t = INF until something is hit
+        int crec = -1;
+        for (uint32_t i = first; i < first + count; ++i) {
+            const uint32_t rec = S.ritems[i];
+            bool hit;
+            float t;
+            if (COUNT) ++st.tris;
+            if (rec < S.ntri) {
+                const float4 *tp = S.tris + 4 * (size_t)rec;
+                hit = tri_test(tp[0], tp[1], tp[2], o, d, t);
+            } else {
+                const PrimHit h = prim_intersect<false>(S.prims + 3 * (size_t)(rec - S.ntri), o, d);
+                hit = h.hit;
+                t = h.t;
+            }
+            if (hit && (crec < 0 || t < ct)) {
+                ct = t;
+                crec = (int)rec;
+            }
+        }
+        if (left | right) {  // a leaf's children are both node 0 = the root and filtered (main.cpp:587, 596)
+            float ld = ref_box_distance(S.rnodes + 4 * (size_t)left, o, d);
+            float rd = ref_box_distance(S.rnodes + 4 * (size_t)right, o, d);
+            if (ld > rd) {  // main.cpp:579-585, the swap as written there
+                const uint32_t l = left;
+                left = right;
+                right = l;
+                ld += rd;
+                rd = ld - rd;
+                ld -= rd;
+            }
+            if (sp < kRefStack) {
+                if (ld < ct) {  // minDistance = closestIntersection.t, main.cpp:571
+                    fr[sp++] = Frame{rd, ct, crec, right};
+                    cur = left;
+                    continue;
+                }
+                if (rd < ct) {
+                    fr[sp++] = Frame{0.f, ct, crec, 0u};
+                    cur = right;
+                    continue;
+                }
+            }
+        }
+        rt = ct;
+        rrec = crec;
+        bool descend = false;
+        while (sp > 0) {  // return into the waiting calls
+            Frame &f = fr[sp - 1];
+            if (rrec >= 0 && (f.rec < 0 || rt < f.t)) {  // main.cpp:589-593, 598-601
+                f.t = rt;
+                f.rec = rrec;
+            }
+            if (f.right != 0u) {  // back from the first child; minDistance is the closest hit's t either way
+                const uint32_t r = f.right;
+                f.right = 0u;
+                if (f.rd < f.t) {
+                    cur = r;
+                    descend = true;
+                    break;
+                }
+            }
+            rt = f.t;
+            rrec = f.rec;
+            --sp;
+        }
+        if (!descend) break;
+    }
+    tOut = rt;
+    recOut = rrec;
+}
+
+// How a kernel answers where the reference's result depends on its traversal order:
+//   kOrderLeaf       own tree, equal distances go to the triangle earlier in leaf order
+//   kOrderRefTies    own tree; a ray that met two primitives at the best distance is traced again by ref_closest_hit
+//   kOrderRefFull    ref_closest_hit for every ray (validation paths)
+enum HitOrder { kOrderLeaf = 0, kOrderRefTies = 1, kOrderRefFull = 2 };
+
+template <bool COUNT, int ORDER = kOrderLeaf>
 __device__ __forceinline__ void closest_hit(const DevScene &S, v3 o, v3 d, int *stack, float &tBest, int &triBest,
                                             TraceStats &st) {
-    Traversal<COUNT> T;
+    if (ORDER == kOrderRefFull) {
+        ref_closest_hit<COUNT>(S, o, d, tBest, triBest, st);
+        return;
+    }
+    Traversal<COUNT, 0, false, false, ORDER == kOrderRefTies> T;
     T.bind(stack);
     T.start(S, o, d);
     while (!T.done()) T.step(S, st);
     tBest = T.tBest;
     triBest = T.triBest;
-    if (S.nprims) analytic_closest(S, o, d, tBest, triBest);
+    bool tie = T.tie;
+    if (S.nprims) tie = analytic_closest(S, o, d, tBest, triBest) || tie;
+    if (ORDER == kOrderRefTies && tie) ref_closest_hit<COUNT>(S, o, d, tBest, triBest, st);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -71,7 +71,29 @@ struct FlatTree {
 // in 64 bytes need as many loads per ray as the two-child tree and measured 3 % faster; this one 8.5 %).
 // Walking it can need more stack than the two-child tree guarantees (three pushes per visit); a ray that
 // runs out is traced again on the two-child tree.
+// The tree the reference itself would build for the scene (ref_tree.cpp), for the kernels that answer in the
+// reference's own traversal order.  Node (64 B = 4 x 16 B): AABB::sizePlusCenter.xyz, negSizePlusCenter.xyz,
+// minPoint.xyz, maxPoint.xyz (main.cpp:113-178), then left, right, firstPrimitiveId, primitiveCount
+// (main.cpp:539-546; a leaf has left = right = 0).  items[i] = the i-th entry of the reference's re-ordered
+// primitive list as a record index: a triangle's position in the leaf-ordered triangle array, or (number of
+// triangle records) + k for analytic primitive k.
+constexpr uint32_t kRefStackEntries = 64;  // frames of the reference-order walker = deepest tree it can follow
+struct RefTree {
+    bool available = false;
+    std::string reason;            // why not, when not available
+    std::vector<uint32_t> nodes;   // nnodes * 16
+    std::vector<uint32_t> items;   // primitive list in the reference's order, as record indices
+    std::vector<uint32_t> order;   // the same list as loader ids (triangle id, or ntri + k)
+    uint32_t nnodes = 0;
+    uint32_t depth = 0;            // deepest node
+    uint32_t nplanes = 0;          // analytic planes at the front of the list, tested at the root
+    double seconds = 0.0;
+};
+// recordOfTriangle: loader id -> position in the leaf-ordered triangle array; nrecords: records in that array.
+void build_ref_tree(const rt_scene_desc &desc, const std::vector<uint32_t> &recordOfTriangle, uint32_t nrecords, RefTree &out);
+
 struct FlatScene {
+    RefTree ref;
     std::vector<uint32_t> nodes;    // nnodes * 8
     std::vector<uint32_t> wide;     // nwide * 12
     uint32_t nwide = 0;

@@ -64,7 +64,8 @@ __device__ __forceinline__ uint32_t tri_loader_id(const DevScene &S, int tri) {
     return __float_as_uint(S.tris[4 * (size_t)tri + 3].x);
 }
 
-template <bool COUNT>
+// REF: every ray is answered by the reference's own walk over the reference's own tree (ref_closest_hit).
+template <bool COUNT, bool REF>
 __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, uint64_t n, const float *__restrict__ o,
                                                        const float *__restrict__ d, uint32_t *__restrict__ prim_id,
                                                        float *__restrict__ tout) {
@@ -76,13 +77,13 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, uint64_t n, co
     float t;
     int tri;
     TraceStats st{0, 0, 0, 0};
-    closest_hit<COUNT>(S, ro, rd, s_stack + threadIdx.x, t, tri, st);
+    closest_hit<COUNT, REF ? kOrderRefFull : kOrderLeaf>(S, ro, rd, s_stack + threadIdx.x, t, tri, st);
     prim_id[i] = tri >= 0 ? tri_loader_id(S, tri) : 0xFFFFFFFFu;
     tout[i] = t;
     if (COUNT) add_counters(S, 0u, st, 0u, true);  // the host adds one segment per ray
 }
 
-template <bool COUNT>
+template <bool COUNT, bool REF>
 __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, uint32_t W, uint32_t H, uint32_t *__restrict__ prim_id,
                                                      float *__restrict__ tout) {
     __shared__ int s_stack[kStack * kBlock];
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, uint32_t W, uint
     float t;
     int tri;
     TraceStats st{0, 0, 0, 0};
-    closest_hit<COUNT>(S, ro, rd, s_stack + threadIdx.x, t, tri, st);
+    closest_hit<COUNT, REF ? kOrderRefFull : kOrderLeaf>(S, ro, rd, s_stack + threadIdx.x, t, tri, st);
     prim_id[pix] = tri >= 0 ? tri_loader_id(S, tri) : 0xFFFFFFFFu;
     tout[pix] = t;
     if (COUNT) add_counters(S, 0u, st, 0u, true);  // the host adds one segment per pixel
@@ -104,7 +105,9 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, uint32_t W, uint
 // One lane owns one pixel and runs its samples back to back; when a path ends the lane starts
 // the next sample in the same loop iteration ("path regeneration"), so lanes of a wave stay
 // busy although their paths have different lengths.
-template <bool COUNT, bool TREE>
+// ORDER (HitOrder): kOrderRefTies: a ray that met two primitives at the best distance is traced again in the
+// reference's order; kOrderRefFull: every ray is (the reference's NaN and beyond-INF hits and its subtree cuts too).
+template <bool COUNT, bool TREE, int ORDER>
 __global__ __launch_bounds__(kBlock) void k_render_mega(DevScene S, rt::RenderParams rp, float *__restrict__ sum) {
     __shared__ int s_stack[kStack * kBlock];
     __shared__ LightCacheStorage s_lights;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(kBlock) void k_render_mega(DevScene S, rt::RenderPa
         }
         float t;
         int tri;
-        closest_hit<COUNT>(S, P.o, P.d, s_stack + threadIdx.x, t, tri, st);
+        closest_hit<COUNT, ORDER>(S, P.o, P.d, s_stack + threadIdx.x, t, tri, st);
         ++segs;
         active = shade_hit<TREE>(S, LC, P, t, tri, lightTests);
         if (!active) acc = acc + P.L;  // color += generateSample(...), main.cpp:1224
@@ -157,7 +160,8 @@ __global__ __launch_bounds__(kBlock) void k_render_mega(DevScene S, rt::RenderPa
 // libstdc++ / glibc sampling code this reproduces the CPU path's radiance sums bit for bit; it is
 // the validation kernel, not the fast one.  rec: [depth][3][stride] words (op | material << 3,
 // wn, pdf), stride = threads of the launch.
-template <bool COUNT, bool TREE>
+// REF: every ray through ref_closest_hit, so that the order-dependent results are the reference's too.
+template <bool COUNT, bool TREE, bool REF>
 __global__ __launch_bounds__(kBlock) void k_render_replay(DevScene S, rt::RenderParams rp, float *__restrict__ sum,
                                                           uint32_t *__restrict__ rec, uint32_t stride) {
     __shared__ int s_stack[kStack * kBlock];
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(kBlock) void k_render_replay(DevScene S, rt::Render
         for (;;) {
             float t;
             int tri;
-            closest_hit<COUNT>(S, P.o, P.d, s_stack + threadIdx.x, t, tri, st);
+            closest_hit<COUNT, REF ? kOrderRefFull : kOrderLeaf>(S, P.o, P.d, s_stack + threadIdx.x, t, tri, st);
             ++segs;
             Vertex V;
             const bool alive = sample_vertex<TREE>(S, LC, P, t, tri, V, lightTests);
@@ -333,9 +337,11 @@ constexpr int kRefill = 20;  // 4: -3 %, 12: -1 %, 16 to 24: within 0.5 %, 32: -
 // -5 % on the Cornell box and -4 % on the 100 k-triangle height field (the later bounces wait for memory and
 // gain most), +-0 on the glass scene, where 61 instead of 4 us per launch go into repeated walks.  Eight waves
 // (17 entries, 64 VGPRs with 15 spilled): +15 %.
+// TIES: a ray whose walk met two primitives at the best distance goes to the `retry` list as well, and
+// wf_extend_retry<REF> answers it in the reference's own order.
 constexpr int kWideStack = 20;
 constexpr int kWideWaves = 7;
-template <bool COUNT, bool PRIMS, bool WIDE>
+template <bool COUNT, bool PRIMS, bool WIDE, bool TIES>
 __global__ __launch_bounds__(kBlock, WIDE ? kWideWaves : 1) void wf_extend(DevScene S, WfView V, const uint32_t *__restrict__ queue_shaded,
                                                      const uint32_t *__restrict__ queue_sorted, SortChoice choice,
                                                      const uint32_t *__restrict__ qcount_in,
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? kWideWaves : 1) void wf_extend(DevSc
     const uint32_t *__restrict__ queue = hit_by_slot ? queue_sorted : queue_shaded;
     __shared__ int s_stack[(WIDE ? kWideStack : kStack) * kBlock];
     __shared__ uint32_t s_xchg[4][128];
-    Traversal<COUNT, kExitLanes, true, WIDE> T;
+    Traversal<COUNT, kExitLanes, true, WIDE, TIES> T;
     T.limit = WIDE && stack_limit > kWideStack ? kWideStack : stack_limit;
     T.xchg = s_xchg[threadIdx.x >> 6];
     const uint32_t count = *qcount_in;
@@ -365,12 +371,17 @@ __global__ __launch_bounds__(kBlock, WIDE ? kWideWaves : 1) void wf_extend(DevSc
     TraceStats st{0, 0, 0, 0};
     for (;;) {
         if (hasRay && T.done()) {
-            if (WIDE && T.overflow) {
+            bool again = WIDE && T.overflow;
+            if (!again) {
+                bool tie = TIES && T.tie;
+                if (PRIMS) tie = (analytic_closest(S, T.o, T.d, T.tBest, T.triBest) || tie) && TIES;
+                again = tie;
+            }
+            if (again) {
                 const uint32_t at = atomicAdd(retry_count, 1u);  // (slot, where its hit goes)
                 retry[2 * (size_t)at] = slot;
                 retry[2 * (size_t)at + 1] = hitAt;
             } else {
-                if (PRIMS) analytic_closest(S, T.o, T.d, T.tBest, T.triBest);
                 V.hit[hitAt] = make_float2(T.tBest, __int_as_float(T.triBest));
                 ++segs;
             }
@@ -448,8 +459,9 @@ __global__ __launch_bounds__(kBlock, WIDE ? kWideWaves : 1) void wf_extend(DevSc
     }
 }
 
-// The rays wf_extend<WIDE> gave up on, one lane each, on the two-child tree (whose height bounds the stack).
-template <bool COUNT>
+// The rays wf_extend gave up on, one lane each: on the two-child tree (whose height bounds the stack), or,
+// REF, by the reference's own walk (scenes whose hits are resolved in the reference's order).
+template <bool COUNT, bool REF>
 __global__ __launch_bounds__(kBlock) void wf_extend_retry(DevScene S, WfView V, const uint32_t *__restrict__ retry,
                                                            const uint32_t *__restrict__ retry_count, uint32_t camera_rays) {
     __shared__ int s_stack[kStack * kBlock];
@@ -467,7 +479,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_retry(DevScene S, WfView V, 
         }
         float t;
         int tri;
-        closest_hit<COUNT>(S, o, d, s_stack + threadIdx.x, t, tri, st);
+        closest_hit<COUNT, REF ? kOrderRefFull : kOrderLeaf>(S, o, d, s_stack + threadIdx.x, t, tri, st);
         V.hit[hitAt] = make_float2(t, __int_as_float(tri));
         ++segs;
     }
@@ -764,6 +776,7 @@ inline uint32_t ceil_blocks(uint64_t n) { return (uint32_t)((n + kBlock - 1) / k
 constexpr uint32_t kPersistentBlocks = 256u * 8u;  // 256 CUs x 8 workgroups for grid-stride kernels
 constexpr uint32_t kExtendBlocks = 256u * 6u;      // 256 CUs x 6 resident workgroups (24 KB of LDS each); the wide walk: kWideWaves
 constexpr uint32_t kRetryGrid = 64;                // the retry list is empty or nearly so
+constexpr uint32_t kRetryGridTies = 1024;          // ... unless faces of the scene coincide (a box standing on a floor: a percent of the rays)
 
 }  // namespace
 
@@ -772,32 +785,37 @@ namespace rt {
 static uint32_t *tune_bounce_host(uint32_t *tune, uint32_t b) { return tune + 8u + 4u * (b < kTuneBounces ? b : kTuneBounces - 1u); }
 
 hipError_t launch_intersect(const DevScene &S, uint64_t n, const float *o, const float *d, uint32_t *prim_id, float *t,
-                            bool count, hipStream_t stream, KernelTimer &timer) {
+                            bool count, bool ref_order, hipStream_t stream, KernelTimer &timer) {
     if (n == 0) return hipSuccess;
     const uint32_t grid = (uint32_t)((n + kBlock - 1) / kBlock);
     timer.begin(kKernClosestHit, stream);
-    if (count) hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(kBlock), 0, stream, S, n, o, d, prim_id, t);
-    else hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(kBlock), 0, stream, S, n, o, d, prim_id, t);
+    auto kern = ref_order ? (count ? k_intersect<true, true> : k_intersect<false, true>)
+                          : (count ? k_intersect<true, false> : k_intersect<false, false>);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, stream, S, n, o, d, prim_id, t);
     timer.end(stream);
     return hipGetLastError();
 }
 
 hipError_t launch_primary(const DevScene &S, uint32_t W, uint32_t H, uint32_t *prim_id, float *t, bool count,
-                          hipStream_t stream, KernelTimer &timer) {
+                          bool ref_order, hipStream_t stream, KernelTimer &timer) {
     const uint32_t grid = pixel_grid(W, H);
     timer.begin(kKernClosestHit, stream);
-    if (count) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), 0, stream, S, W, H, prim_id, t);
-    else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), 0, stream, S, W, H, prim_id, t);
+    auto kern = ref_order ? (count ? k_primary<true, true> : k_primary<false, true>)
+                          : (count ? k_primary<true, false> : k_primary<false, false>);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, stream, S, W, H, prim_id, t);
     timer.end(stream);
     return hipGetLastError();
 }
 
-hipError_t launch_render_mega(const DevScene &S, const RenderParams &rp, float *radiance_sum, bool count,
+hipError_t launch_render_mega(const DevScene &S, const RenderParams &rp, float *radiance_sum, bool count, int order,
                               hipStream_t stream, KernelTimer &timer) {
     const uint32_t grid = pixel_grid(rp.W, rp.H);
     timer.begin(kKernMega, stream);
-    auto kern = S.light_tree ? (count ? k_render_mega<true, true> : k_render_mega<false, true>)
-                             : (count ? k_render_mega<true, false> : k_render_mega<false, false>);
+#define RT_MEGA(O_)                                                                              \
+    (S.light_tree ? (count ? k_render_mega<true, true, O_> : k_render_mega<false, true, O_>)     \
+                  : (count ? k_render_mega<true, false, O_> : k_render_mega<false, false, O_>))
+    auto kern = order == kOrderRefFull ? RT_MEGA(kOrderRefFull) : order == kOrderRefTies ? RT_MEGA(kOrderRefTies) : RT_MEGA(kOrderLeaf);
+#undef RT_MEGA
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, stream, S, rp, radiance_sum);
     timer.end(stream);
     return hipGetLastError();
@@ -809,11 +827,13 @@ uint64_t replay_words(const RenderParams &rp) {
 }
 
 hipError_t launch_render_replay(const DevScene &S, const RenderParams &rp, float *radiance_sum, uint32_t *rec, bool count,
-                                hipStream_t stream, KernelTimer &timer) {
+                                bool ref_order, hipStream_t stream, KernelTimer &timer) {
     const uint32_t grid = pixel_grid(rp.W, rp.H);
     timer.begin(kKernMega, stream);
-    auto kern = S.light_tree ? (count ? k_render_replay<true, true> : k_render_replay<false, true>)
-                             : (count ? k_render_replay<true, false> : k_render_replay<false, false>);
+    auto kern = ref_order ? (S.light_tree ? (count ? k_render_replay<true, true, true> : k_render_replay<false, true, true>)
+                                          : (count ? k_render_replay<true, false, true> : k_render_replay<false, false, true>))
+                          : (S.light_tree ? (count ? k_render_replay<true, true, false> : k_render_replay<false, true, false>)
+                                          : (count ? k_render_replay<true, false, false> : k_render_replay<false, false, false>));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, stream, S, rp, radiance_sum, rec, grid * kBlock);
     timer.end(stream);
     return hipGetLastError();
@@ -860,15 +880,20 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
             const SortChoice next{sort ? (uint32_t)wb.sort : 0u, tune_bounce_host(wb.tuner, b + 1) + 2};
             timer.begin(kKernExtend, stream);
             uint32_t *retry = wb.retry, *retryCount = wb.qcount + 2;
-            auto ext = wb.wide ? (S.nprims ? (count ? wf_extend<true, true, true> : wf_extend<false, true, true>)
-                                           : (count ? wf_extend<true, false, true> : wf_extend<false, false, true>))
-                               : (S.nprims ? (count ? wf_extend<true, true, false> : wf_extend<false, true, false>)
-                                           : (count ? wf_extend<true, false, false> : wf_extend<false, false, false>));
+#define RT_EXT(W_, T_)                                                                                     \
+    (S.nprims ? (count ? wf_extend<true, true, W_, T_> : wf_extend<false, true, W_, T_>)                   \
+              : (count ? wf_extend<true, false, W_, T_> : wf_extend<false, false, W_, T_>))
+            auto ext = wb.wide ? (wb.ties ? RT_EXT(true, true) : RT_EXT(true, false))
+                               : (wb.ties ? RT_EXT(false, true) : RT_EXT(false, false));
+#undef RT_EXT
             hipLaunchKernelGGL(ext, dim3(egrid), dim3(kBlock), 0, stream, S, V, qshade, qsorted, traced, wb.qcount + in,
                                wb.qcount + out, wb.cursors, retry, retryCount, wb.stack_limit, tune, b, wb.sort_min_rays);
-            if (wb.wide)
-                hipLaunchKernelGGL(count ? wf_extend_retry<true> : wf_extend_retry<false>, dim3(kRetryGrid), dim3(kBlock), 0, stream, S,
-                                   V, retry, retryCount, b == 0 ? 1u : 0u);
+            if (wb.wide || wb.ties) {
+                auto again = wb.ties ? (count ? wf_extend_retry<true, true> : wf_extend_retry<false, true>)
+                                     : (count ? wf_extend_retry<true, false> : wf_extend_retry<false, false>);
+                hipLaunchKernelGGL(again, dim3(wb.ties ? kRetryGridTies : kRetryGrid), dim3(kBlock), 0, stream, S, V, retry, retryCount,
+                                   b == 0 ? 1u : 0u);
+            }
             timer.end(stream);
             timer.begin(kKernShade, stream);
             auto shade = !S.light_tree ? (qshade ? wf_shade<false, false> : wf_shade<false, true>)

@@ -104,21 +104,26 @@ struct WavefrontBuffers {
     uint32_t sort_min_rays = 1u << 20;  // mode 2: shorter queues are not worth three launches
     uint32_t *tuner = nullptr;  // kWfTuneWords words, zero when allocated and then the tuner's own (mode 2)
     bool wide = true;         // wf_extend walks the four-child tree
+    bool ties = false;        // rays that met two primitives at the best distance are traced again in the reference's order
     int stack_limit = 24;     // entries of the traversal stack the wide walk may use (the kernel caps it at its own 20; less only in tests)
     uint32_t *qcount = nullptr; // kWfCountWords words: queue lengths, retry count (device)
     uint32_t *cursors = nullptr; // work cursors of the extend kernel, kWfCursorWords words
 };
 
 hipError_t launch_intersect(const rtd::DevScene &S, uint64_t n, const float *o, const float *d, uint32_t *prim_id,
-                            float *t, bool count, hipStream_t stream, KernelTimer &timer);
+                            float *t, bool count, bool ref_order, hipStream_t stream, KernelTimer &timer);
 hipError_t launch_primary(const rtd::DevScene &S, uint32_t W, uint32_t H, uint32_t *prim_id, float *t, bool count,
-                          hipStream_t stream, KernelTimer &timer);
-hipError_t launch_render_mega(const rtd::DevScene &S, const RenderParams &rp, float *radiance_sum, bool count,
+                          bool ref_order, hipStream_t stream, KernelTimer &timer);
+// ref_order (only for scenes that hold the reference's tree, S.rnodes): results that depend on the reference's
+// traversal order are resolved as the reference resolves them, by its own walk (ref_closest_hit) for every ray.
+// The megakernel takes a rtd::HitOrder: own tree / own tree + the reference's walk for rays that met two
+// primitives at the best distance / the reference's walk for every ray.
+hipError_t launch_render_mega(const rtd::DevScene &S, const RenderParams &rp, float *radiance_sum, bool count, int order,
                               hipStream_t stream, KernelTimer &timer);
 // Replay kernel (reference RNG stream, backward evaluation): words of per-lane vertex records it needs.
 uint64_t replay_words(const RenderParams &rp);
 hipError_t launch_render_replay(const rtd::DevScene &S, const RenderParams &rp, float *radiance_sum, uint32_t *rec,
-                                bool count, hipStream_t stream, KernelTimer &timer);
+                                bool count, bool ref_order, hipStream_t stream, KernelTimer &timer);
 hipError_t launch_render_wavefront(const rtd::DevScene &S, const RenderParams &rp, float *radiance_sum,
                                    const WavefrontBuffers &wb, uint32_t slots, bool count, hipStream_t stream,
                                    KernelTimer &timer);

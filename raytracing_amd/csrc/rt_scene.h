@@ -18,6 +18,9 @@ struct rt_scene {
     float4 *d_lrecs = nullptr;
     rtd::DevMaterial *d_mats = nullptr;
     float4 *d_prims = nullptr;  // analytic primitives, 3 x float4 each
+    float4 *d_rnodes = nullptr;   // the reference's own tree (FlatScene::ref), when the scene is within its limits
+    uint32_t *d_ritems = nullptr;
+    int hit_order = RT_HITS_LEAF_ORDER;  // RT_HITS_*: how order-dependent hits are resolved (rt_scene_set_hit_order)
     unsigned long long *d_counters = nullptr;
     rt::WavefrontBuffers wf;
     uint32_t *d_replay = nullptr;  // vertex records of the replay kernel, grown to the largest request

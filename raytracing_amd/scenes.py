@@ -206,9 +206,11 @@ def _quat_axis_angle(axis, angle):
 # ------------------------------------------------------------------------------------------
 # Scenes
 # ------------------------------------------------------------------------------------------
-def cornell_box(path):
+def cornell_box(path, on_floor=False):
     """36 triangles: 5 diffuse wall quads, one emissive ceiling quad, a metallic box and a
-    dielectric box (TRS nodes under one parent).  Camera at (0, 0, 3.4) looking down -z."""
+    dielectric box (TRS nodes under one parent).  Camera at (0, 0, 3.4) looking down -z.
+    on_floor: the boxes stand ON the floor (their bottom faces lie in the floor plane, as objects in
+    scene files usually do) instead of floating 2 mm above it."""
     g = GltfBuilder()
     white = g.material(DIFFUSER, (0.73, 0.73, 0.73))
     red = g.material(DIFFUSER, (0.65, 0.05, 0.05))
@@ -236,9 +238,12 @@ def cornell_box(path):
     # The boxes float 2 mm above the floor: a box face lying IN the floor plane gives every ray that leaves the
     # glass box downwards two hits at exactly the same distance, and which one wins depends on the order a tree
     # is walked in (the reference's strict minimum, main.cpp:563-571, keeps the first it meets).
-    g.node(mesh=cube_m, translation=(-0.38, -0.398, -0.35), rotation=_quat_axis_angle((0, 1, 0), 0.32),
+    # With on_floor the two hits are there: only a traversal that resolves them in the reference's order renders
+    # that scene as the reference does.
+    lift = 0.0 if on_floor else 0.002
+    g.node(mesh=cube_m, translation=(-0.38, -0.4 + lift, -0.35), rotation=_quat_axis_angle((0, 1, 0), 0.32),
            scale=(0.58, 1.2, 0.58))                  # 3: tall mirror box
-    g.node(mesh=cube_g, translation=(0.4, -0.698, 0.3), rotation=_quat_axis_angle((0, 1, 0), -0.3),
+    g.node(mesh=cube_g, translation=(0.4, -0.7 + lift, 0.3), rotation=_quat_axis_angle((0, 1, 0), -0.3),
            scale=(0.56, 0.6, 0.56))                  # 4: glass box
     cam = g.camera(0.6911)
     g.node(camera=cam, translation=(0.0, 0.0, 3.4))  # 5
@@ -384,6 +389,7 @@ def emissive_mesh_scene(path, subdiv=3, lamps=3):
 SCENES = {
     "emissive": emissive_mesh_scene,
     "cornell": cornell_box,
+    "cornell_onfloor": lambda path, **kw: cornell_box(path, on_floor=True, **kw),
     "heightfield100k": heightfield_scene,
     "spheres1m": sphere_field_scene,
     "glass": glass_scene,

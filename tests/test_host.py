@@ -521,3 +521,63 @@ def test_analytic_primitive_validation(scene_dir):
     with pytest.raises(rt.RtError) as ei:
         rt.build_flat(rt.HostScene(base.tri_verts, base.tri_material, base.materials, base.camera, prims=many))
     assert ei.value.code == -4
+
+
+@pytest.mark.parametrize("name,kw,with_prims", [
+    ("cornell", {}, False),
+    ("cornell_onfloor", {}, True),
+    ("glass", {"grid": 3, "subdiv": 2}, False),
+    ("heightfield100k", {"nx": 40, "nz": 40}, True),
+    ("spheres1m", {"n_spheres": 30, "subdiv": 2, "ground": 12}, False),
+])
+def test_reference_tree_equals_the_oracles_build(scene_dir, oracle_mod, name, kw, with_prims):
+    """The host builds the tree the reference itself would build (BVH::build, main.cpp:552-558, 608-686) for the
+    kernels that answer in the reference's traversal order.  Against the oracle's restatement of that build: the
+    same nodes in the same numbering, the same boxes bit for bit, the same primitive order inside every leaf --
+    with analytic primitives too (planes at the root, ellipsoids and boxes under their calculateAABB boxes)."""
+    import raytracing_amd as rt
+    base = rt.load_gltf(make_scene(scene_dir, name, **kw), 64, 48)
+    prims = None
+    if with_prims:
+        rng = np.random.RandomState(3)
+        prims = np.zeros(9, dtype=rt.PRIMITIVE_DTYPE)
+        prims["type"] = [rt.PRIM_ELLIPSOID, rt.PRIM_PLANE, rt.PRIM_BOX, rt.PRIM_BOX, rt.PRIM_ELLIPSOID, rt.PRIM_PLANE,
+                         rt.PRIM_ELLIPSOID, rt.PRIM_BOX, rt.PRIM_ELLIPSOID]
+        prims["position"] = rng.uniform(-0.8, 0.8, size=(9, 3))
+        q = rng.normal(size=(9, 4))
+        prims["rotation"] = q / np.linalg.norm(q, axis=1, keepdims=True)
+        prims["param"] = rng.uniform(0.05, 0.4, size=(9, 3))
+        emits = np.linalg.norm(base.materials["emission"], axis=1) > 1e-4
+        prims["material"] = int(np.flatnonzero(~emits)[0])
+    host = rt.HostScene(base.tri_verts, base.tri_material, base.materials, base.camera, prims=prims)
+    d = host.as_dict()
+    orc = oracle_mod.OracleScene(d["tri_verts"], d["tri_material"], d["materials"], d["camera"], prims=prims,
+                                 prims_in_tree=True)
+    assert orc.info()["unsplittable"] == 0
+    ref = rt.build_flat(host)["ref_tree"]
+    assert ref is not None
+    nodes, boxes, items = orc.tree()
+    assert ref["nodes"].shape[0] == nodes.shape[0] and ref["depth"] == orc.info()["max_depth"]
+    assert np.array_equal(ref["nodes"][:, 12:], nodes)                      # left, right, first, count
+    assert np.array_equal(ref["nodes"][:, :12], boxes.view(np.uint32))      # the four corner vectors of AABB
+    assert np.array_equal(ref["order"], items)
+    assert ref["nplanes"] == (2 if with_prims else 0)
+    if with_prims:                                                          # planes lead the list; the root tests them
+        ntri = host.tri_material.shape[0]
+        assert set(ref["order"][:2]) == {ntri + 1, ntri + 5} and nodes[0, 2] == 0 and nodes[0, 3] >= 2
+
+
+def test_reference_tree_limits():
+    """Beyond what the reference can hold (uint16_t ids, main.cpp:541-544) or build (a node of more than four
+    primitives that no split improves, main.cpp:675-679) there is no reference tree: the build says why and the
+    scene keeps the kernels' own hit order."""
+    import raytracing_amd as rt
+    mats = np.zeros(1, dtype=rt.api.MATERIAL_DTYPE)
+    mats["color"] = 0.5
+    cam = dict(position=[0, 0, 3], right=[1, 0, 0], up=[0, 1, 0], forward=[0, 0, -1], tan_x=0.5, tan_y=0.5)
+    rng = np.random.RandomState(2)
+    big = (rng.uniform(-1, 1, size=(65536, 1, 3)) + rng.uniform(-0.01, 0.01, size=(65536, 3, 3))).astype(np.float32)
+    assert rt.build_flat(rt.HostScene(big, np.zeros(65536, np.uint32), mats, cam))["ref_tree"] is None
+    assert rt.build_flat(rt.HostScene(big[:30000], np.zeros(30000, np.uint32), mats, cam))["ref_tree"] is not None
+    same = np.repeat(big[:1], 6, axis=0)                                    # six copies of one triangle: no split helps
+    assert rt.build_flat(rt.HostScene(same, np.zeros(6, np.uint32), mats, cam))["ref_tree"] is None
