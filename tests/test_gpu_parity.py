@@ -768,6 +768,50 @@ def test_million_triangle_scene_matches_oracle_on_primary_rays(scene_dir, oracle
     assert gpu.counters()["segments"] == c0["segments"]
 
 
+def test_config4_full_size_frame_properties(scene_dir, oracle_mod, monkeypatch):
+    """BASELINE config 4's own frame -- the scene and image size the bench line is measured on: 1 006 600
+    triangles, 1920x1080, depth 8, the scene's default ray sorting (tuned on the device), the four-child walk.  With
+    a path budget of four frames 12 samples take three passes whose queues stay above 2^20 rays for several
+    bounces, so the tuner goes through its states (unsorted, sorted, chosen) inside the call.  The oracle cannot
+    render this frame, so it is checked through properties (generatePixel's sum, main.cpp:1220-1225):
+    (i) bit-equal to the same render with sorting off; (ii) sample ranges add up across a pass boundary;
+    (iii) a second call (the tuner in another state) gives the same bits; (iv) wavefront and megakernel agree to
+    1e-5 on 2 samples; (v) the sort kernels did real work; (vi) ray segments per sample within 3 % of the
+    oracle's on the same scene at 480x270."""
+    import raytracing_amd as rt
+    W, H, depth = 1920, 1080, 8
+    monkeypatch.delenv("RT_WF_SORT", raising=False)
+    monkeypatch.delenv("RT_WF_SORT_MIN_RAYS", raising=False)
+    monkeypatch.setenv("RT_WF_PATHS", str(4 * W * H))
+    host, gpu, orc = _load(scene_dir, oracle_mod, "spheres1m", W, H)
+    assert gpu.stats()["ntri"] == 1006600 and gpu.stats()["hit_order"] == rt.HITS_LEAF_ORDER   # beyond the reference's limits
+    gpu.set_timing(True)
+    gpu.reset_counters()
+    full = gpu.render(W, H, 12, max_depth=depth, rng_mode=1, seed=0x5EED, pipeline=rt.PIPE_WAVEFRONT)
+    segs = gpu.counters()["segments"]
+    times = gpu.kernel_times()
+    gpu.set_timing(False)
+    print("kernel times (ms, launches):", times)
+    assert times["sort"][1] > 0 and times["sort"][0] > 0.5, times["sort"]     # (v) ms: an idle sort launch takes 0.01
+    assert np.isfinite(full).all() and (full >= 0).all() and full.sum() > 0
+    again = gpu.render(W, H, 12, max_depth=depth, rng_mode=1, seed=0x5EED, pipeline=rt.PIPE_WAVEFRONT)
+    assert np.array_equal(again, full)                                        # (iii)
+    a = gpu.render(W, H, 10, max_depth=depth, rng_mode=1, seed=0x5EED, spp_begin=0, pipeline=rt.PIPE_WAVEFRONT)
+    b = gpu.render(W, H, 2, max_depth=depth, rng_mode=1, seed=0x5EED, spp_begin=10, pipeline=rt.PIPE_WAVEFRONT)
+    assert np.allclose(a + b, full, rtol=1e-5, atol=1e-6)                     # (ii)
+    mega = gpu.render(W, H, 2, max_depth=depth, rng_mode=1, seed=0x5EED, spp_begin=10, pipeline=rt.PIPE_MEGAKERNEL)
+    assert np.allclose(mega, b, rtol=1e-5, atol=1e-6)                         # (iv)
+    monkeypatch.setenv("RT_WF_SORT", "0")
+    with rt.Scene(host, device=0) as plain:
+        plain.set_timing(True)
+        unsorted = plain.render(W, H, 12, max_depth=depth, rng_mode=1, seed=0x5EED, pipeline=rt.PIPE_WAVEFRONT)
+        assert plain.kernel_times()["sort"][1] == 0
+    assert np.array_equal(unsorted, full)                                     # (i)
+    _, c_small = orc.render(W // 4, H // 4, 2, max_depth=depth, rng_mode=1, seed=0x5EED)
+    per_small = c_small["segments"] / float((W // 4) * (H // 4) * 2)
+    assert abs(segs / float(W * H * 12) - per_small) < 0.03 * per_small         # (vi)
+
+
 def test_counting_launches_match_oracle_semantics(scene_dir, oracle_mod):
     """The counted launches report nodes / triangle tests per ray for the roofline model.  Segment
     and light-pdf test counts are properties of the estimator and equal the oracle's."""
