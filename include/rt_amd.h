@@ -324,7 +324,11 @@ int rt_scene_reserve(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_
  * process ends) instead of scene-owned allocations, and the call makes no hipMalloc / hipFree.
  * Limit: width * height <= RT_NOALLOC_MAX_PIXELS (one 1920x1080 frame fits), RT_ERR_LIMIT beyond;
  * smaller images keep up to 64 frames of samples in flight.  Every call on a GPU shares that GPU's
- * array, whatever the scene: calls that overlap on one GPU (two streams, two threads) race. */
+ * array, whatever the scene: calls that overlap on one GPU (two streams, two threads) race.  The ray-sorting
+ * tuner's books live in the array too and are kept from call to call (per GPU, not per scene: after a change of
+ * scene it re-learns over a few passes; results do not depend on it).  The call can be captured into a HIP graph
+ * (hipStreamBeginCapture on `stream` before it, hipStreamEndCapture after): it enqueues one memset and kernels,
+ * and nothing else. */
 #define RT_NOALLOC_MAX_PIXELS (1u << 21)
 int rt_render_noalloc_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_begin, uint32_t spp_count,
                           uint32_t max_depth, uint32_t seed, float *d_radiance_sum, void *stream);
@@ -364,7 +368,11 @@ int rt_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_
 /* ---- counters ---- */
 int rt_set_counting(rt_scene *s, int enable); /* 1: launches also count nodes / triangle tests (slower) */
 int rt_counters_reset(rt_scene *s, void *stream);
-int rt_counters_read(rt_scene *s, rt_counters *out); /* synchronises the device */
+/* Synchronises the device.  Counting launches also watch every ray's walk: one that takes more rounds or node
+ * visits than four times the tree's nodes and leaves is cut short, and this call then fills `out` and returns
+ * RT_ERR_INVALID (a broken tree or traversal state machine would otherwise spin forever; only counting launches
+ * carry the check, the timed kernels do not pay for it). */
+int rt_counters_read(rt_scene *s, rt_counters *out);
 
 /* ---- per-kernel device time (HIP events on the launch stream) ----
  * rt_set_timing(s, 1) synchronises, clears the totals and makes every later launch record an event

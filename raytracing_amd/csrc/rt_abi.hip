@@ -397,6 +397,10 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
             s->stack_limit = n < 0 ? 0 : (n > rtd::kStack ? rtd::kStack : n);
         }
     }
+    // no walk visits a node or a leaf twice: nodes + leaves bounds the rounds and visits of one ray's walk (the wide
+    // walk's retry included); four times that is the counting launches' alarm (TraceStats::runaway)
+    v.step_bound = 4u * (f.nnodes + f.nslots + f.light_nnodes) + 64u;
+    if (const char *e = std::getenv("RT_TEST_STEP_BOUND")) v.step_bound = (uint32_t)std::strtoul(e, nullptr, 10);  // tests: trip the alarm
     v.has_background = 0u;
     for (int k = 0; k < 3; ++k) {
         v.background[k] = desc->background[k];
@@ -620,9 +624,12 @@ int rt_render_noalloc_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t
     wb.qcount = reinterpret_cast<uint32_t *>(base + kScratchQcount);
     wb.cursors = reinterpret_cast<uint32_t *>(base + kScratchCursors);
     wb.tuner = reinterpret_cast<uint32_t *>(base + kScratchTuner);
-    // the array keeps the previous call's contents: counters and cursors start from zero, the records
-    // and queues are rewritten by wf_generate / wf_shade before they are read
-    RT_HIP(hipMemsetAsync(base + kScratchQcount, 0, kScratchBytes - kScratchQcount, (hipStream_t)stream));
+    // the array keeps the previous call's contents: counters, cursors and the cell histogram start from zero, the
+    // records and queues are rewritten by wf_generate / wf_shade before they are read.  The sort tuner's books
+    // (zero when the code object is loaded) are kept from call to call like a scene's own are, so that a loop of
+    // short calls reaches a decision; they are per GPU here, not per scene: after a change of scene the running
+    // means take a few passes to follow (a matter of speed only, the sums do not depend on what is sorted).
+    RT_HIP(hipMemsetAsync(base + kScratchQcount, 0, kScratchTuner - kScratchQcount, (hipStream_t)stream));
     rt::RenderParams rp{width, height, spp_begin, spp_count, max_depth, RT_RNG_COUNTER, seed};
     rt::KernelTimer untimed;  // event pairs of rt_set_timing would create events: not here
     RT_HIP(rt::launch_render_wavefront(s->view, rp, d_radiance_sum, wb, slots, s->counting, (hipStream_t)stream, untimed));
@@ -779,15 +786,19 @@ int rt_counters_read(rt_scene *s, rt_counters *out) {
     std::vector<unsigned long long> raw(kCounterWords);
     RT_HIP(hipDeviceSynchronize());
     RT_HIP(hipMemcpy(raw.data(), s->d_counters, kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long h[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int sh = 0; sh < rtd::kCounterShards; ++sh)
-        for (int k = 0; k < 6; ++k) h[k] += raw[(size_t)sh * rtd::kCounterStride + k];
+        for (int k = 0; k < 7; ++k) h[k] += raw[(size_t)sh * rtd::kCounterStride + k];
     out->segments = h[0] + s->host_segments;
     out->nodes = h[1];
     out->tri_tests = h[2];
     out->light_tests = h[3];
     out->node_lane_slots = h[4];
     out->tri_lane_slots = h[5];
+    if (h[6])
+        return fail(RT_ERR_INVALID, "rt_counters_read: " + std::to_string(h[6]) +
+                                        " workgroup(s) of a counting launch cut a ray's walk short at the step bound: the "
+                                        "traversal state machine or the tree is broken");
     return RT_OK;
 }
 

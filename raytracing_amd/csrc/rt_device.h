@@ -137,6 +137,7 @@ struct DevScene {
     float background[3];  // InputData::backgroundColor (main.cpp:694): radiance of a ray that hits nothing
     uint32_t has_background;  // any component nonzero
     float bin_scale[3];   // (position - grid_origin) * bin_scale = coordinate in units of one ray-sorting cell
+    uint32_t step_bound;  // counting launches: no ray's walk can legitimately take more rounds / node visits than this
 };
 
 // Ray-sorting cells: the node grid's extent cut into 2^kBinBits cells per axis, numbered in Morton order.
@@ -164,6 +165,10 @@ struct TraceStats {
     // lane occupancy of the two traversal phases (COUNT builds only): iterations this lane was active
     // in, and iterations its wave ran (the maximum over the wave's lanes), summed over phases
     uint32_t nodeWave, triWave;
+    // counting launches only: a walk exceeded DevScene::step_bound and was cut short.  The walk ends when a lane
+    // holds neither a node nor a leaf; that rests on one invariant -- a leaf reference (negative) may sit in
+    // `cur` only while `leaf` holds another one -- and a state that breaks it would spin forever.
+    uint32_t runaway;
 };
 
 __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
@@ -293,6 +298,11 @@ struct Traversal {
         sp = 0;
     }
     __device__ __forceinline__ bool done() const { return cur == kSentinel && leaf == 0; }
+    // Counting launches: gives the walk up and says so (TraceStats::runaway)
+    __device__ __forceinline__ void abandon(TraceStats &st) {
+        idle();
+        st.runaway = 1u;
+    }
     // Strict minimum (main.cpp:563-571).  Two triangles at exactly the same distance (a ray through a shared
     // edge, two coincident faces): the reference keeps whichever its own tree meets first.  Without TIES the one
     // earlier in leaf order wins, whatever tree is walked in whatever order, so that every kernel names the same
@@ -354,7 +364,13 @@ struct Traversal {
                 // inside the margin of gn / gf (four times the single-rounding bound).
                 const uint4 *np = S.wide + 3 * (size_t)cur;
                 const uint4 n0 = np[0], n1 = np[1], n3 = np[2];
-                if (COUNT) ++st.nodes;
+                if (COUNT) {
+                    ++st.nodes;
+                    if (st.nodes - nodes0 > S.step_bound) {
+                        abandon(st);
+                        break;
+                    }
+                }
                 const float fox = (float)(n1.z & 0xffffu), foy = (float)(n1.z >> 16), foz = (float)(n1.w & 0xffffu);
                 const float ax = __builtin_ldexpf(ga.x, (int)((n1.w >> 16) & 15u)), ay = __builtin_ldexpf(ga.y, (int)((n1.w >> 20) & 15u)),
                             az = __builtin_ldexpf(ga.z, (int)((n1.w >> 24) & 15u));
@@ -400,7 +416,13 @@ struct Traversal {
             }
             const uint4 *np = S.nodes + 2 * (size_t)cur;
             const uint4 n0 = np[0], n1 = np[1];
-            if (COUNT) ++st.nodes;
+            if (COUNT) {
+                ++st.nodes;
+                if (st.nodes - nodes0 > S.step_bound) {
+                    abandon(st);
+                    break;
+                }
+            }
             // Conservative slab test on the node's 16-bit grid boxes.  The host rounded every box
             // outward and added two guard cells per side, far more than the rounding of these FMAs
             // (a few ulps of the scene's extent), so no box is thinner than four cells and plain
@@ -767,7 +789,11 @@ __device__ __forceinline__ void closest_hit(const DevScene &S, v3 o, v3 d, int *
     Traversal<COUNT, 0, false, false, ORDER == kOrderRefTies> T;
     T.bind(stack);
     T.start(S, o, d);
-    while (!T.done()) T.step(S, st);
+    uint32_t rounds = 0;
+    while (!T.done()) {
+        T.step(S, st);
+        if (COUNT && ++rounds > S.step_bound) T.abandon(st);
+    }
     tBest = T.tBest;
     triBest = T.triBest;
     bool tie = T.tie;

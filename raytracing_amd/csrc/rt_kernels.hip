@@ -54,6 +54,7 @@ __device__ __forceinline__ void add_counters(const DevScene &S, uint32_t segs, c
         atomicAdd(&c[2], (unsigned long long)st.tris);
         atomicAdd(&c[4], (unsigned long long)st.nodeWave);
         atomicAdd(&c[5], (unsigned long long)st.triWave);
+        if (st.runaway) atomicAdd(&c[6], 1ull);
     }
     if (lights) atomicAdd(&c[3], (unsigned long long)lights);
 }
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, uint64_t n, co
     const v3 rd = mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     float t;
     int tri;
-    TraceStats st{0, 0, 0, 0};
+    TraceStats st{0, 0, 0, 0, 0};
     closest_hit<COUNT, REF ? kOrderRefFull : kOrderLeaf>(S, ro, rd, s_stack + threadIdx.x, t, tri, st);
     prim_id[i] = tri >= 0 ? tri_loader_id(S, tri) : 0xFFFFFFFFu;
     tout[i] = t;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, uint32_t W, uint
     const v3 ro = mk(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]);
     float t;
     int tri;
-    TraceStats st{0, 0, 0, 0};
+    TraceStats st{0, 0, 0, 0, 0};
     closest_hit<COUNT, REF ? kOrderRefFull : kOrderLeaf>(S, ro, rd, s_stack + threadIdx.x, t, tri, st);
     prim_id[pix] = tri >= 0 ? tri_loader_id(S, tri) : 0xFFFFFFFFu;
     tout[pix] = t;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(kBlock) void k_render_mega(DevScene S, rt::RenderPa
     v3 acc = mk(0.f, 0.f, 0.f);
     uint32_t s = 0, segs = 0, lightTests = 0;
     bool active = false;
-    TraceStats st{0, 0, 0, 0};
+    TraceStats st{0, 0, 0, 0, 0};
     for (;;) {
         if (!active) {
             if (s >= rp.spp_count) break;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void k_render_replay(DevScene S, rt::Render
     P.L = mk(0.f, 0.f, 0.f);
     v3 acc = mk(0.f, 0.f, 0.f);
     uint32_t segs = 0, lightTests = 0;
-    TraceStats st{0, 0, 0, 0};
+    TraceStats st{0, 0, 0, 0, 0};
     for (uint32_t s = 0; s < rp.spp_count; ++s) {
         if (rp.rng_mode == 1) P.rng = rng_seed(counter_seed(pix, rp.spp_begin + s, rp.seed));
         P.d = primary_direction(S, px, py, rp.W, rp.H, P.rng);
@@ -364,11 +365,12 @@ __global__ __launch_bounds__(kBlock, WIDE ? kWideWaves : 1) void wf_extend(DevSc
     T.idle();
     T.bind(s_stack + threadIdx.x);
     uint32_t slot = 0, hitAt = 0, segs = 0;  // path slot of this lane's ray, and where its hit goes
+    uint32_t rounds = 0;                      // counting launches: rounds this lane's ray has been walking
     bool hasRay = false;
     uint32_t chunkNext = 0, chunkEnd = 0;  // wave-uniform
     uint32_t shard = blockIdx.x % kShards, dry = 0;  // wave-uniform: current shard, shards found empty in a row
     bool exhausted = false;                // wave-uniform: every shard ran dry
-    TraceStats st{0, 0, 0, 0};
+    TraceStats st{0, 0, 0, 0, 0};
     for (;;) {
         if (hasRay && T.done()) {
             bool again = WIDE && T.overflow;
@@ -427,14 +429,16 @@ __global__ __launch_bounds__(kBlock, WIDE ? kWideWaves : 1) void wf_extend(DevSc
                         T.start(S, mk(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]), mk(r0.x, r0.y, r0.z));
                     }
                     hasRay = true;
+                    rounds = 0;
                 }
                 chunkNext += take;
                 given += take;
             }
         }
         T.step(S, st);
+        if (COUNT && hasRay && ++rounds > S.step_bound) T.abandon(st);
     }
-    if (segs) add_counters(S, segs, st, 0u, COUNT);
+    if (segs || (COUNT && st.runaway)) add_counters(S, segs, st, 0u, COUNT);
     if (tune && last_workgroup(tune)) {  // the tuner: file this bounce's cost, decide the next bounce
         const unsigned long long now = wall_clock64(), mark = *reinterpret_cast<const unsigned long long *>(tune);
         if (!COUNT && bounce >= 2u && bounce < kTuneBounces && count) {  // (the counting instantiation is slower: not filed)
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_retry(DevScene S, WfView V, 
     __shared__ int s_stack[kStack * kBlock];
     const uint32_t count = *retry_count;
     uint32_t segs = 0;
-    TraceStats st{0, 0, 0, 0};
+    TraceStats st{0, 0, 0, 0, 0};
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < count; k += gridDim.x * kBlock) {
         const uint32_t slot = retry[2 * (size_t)k], hitAt = retry[2 * (size_t)k + 1];
         const float4 r0 = camera_rays ? V.lum[slot] : V.ray[2 * (size_t)slot];
@@ -632,7 +636,7 @@ __global__ __launch_bounds__(kBlock, TREE ? (LSTACK == kLightStackShort ? 5 : 1)
             __syncthreads();
         }
     }
-    if (lightTests) add_counters(S, 0u, TraceStats{0, 0, 0, 0}, lightTests, false);
+    if (lightTests) add_counters(S, 0u, TraceStats{0, 0, 0, 0, 0}, lightTests, false);
     if (tune && last_workgroup(tune)) *reinterpret_cast<unsigned long long *>(tune) = wall_clock64();  // the tuner's time mark
 }
 

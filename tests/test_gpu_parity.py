@@ -840,6 +840,53 @@ def test_counting_launches_match_oracle_semantics(scene_dir, oracle_mod):
     assert c["nodes"] < c_o["nodes"]
 
 
+def test_counting_launches_watch_the_walks(oracle_mod, monkeypatch):
+    """A ray's walk ends when its lane holds neither a node nor a leaf, which rests on an invariant of the
+    traversal state machine; a state that broke it would spin a kernel forever.  The counting launches bound
+    every walk (four times the tree's nodes and leaves) and rt_counters_read reports a walk that hit the bound.
+    On triangle soups, every kernel family: no alarm.  With the bound forced to 3 the alarm is raised -- the
+    plumbing works -- and the launch still ends."""
+    import raytracing_amd as rt
+    rng = np.random.RandomState(8)
+    n = 4000
+    tri = (rng.uniform(-1, 1, size=(n, 1, 3)) + rng.uniform(-0.2, 0.2, size=(n, 3, 3))).astype(np.float32)
+    mats = np.zeros(3, dtype=rt.api.MATERIAL_DTYPE)
+    mats["color"], mats["type"], mats["ior"] = 0.7, [0, 1, 2], 1.5
+    mats["emission"][0] = (2, 2, 2)
+    which = rng.randint(0, 3, n).astype(np.uint32)
+    cam = dict(position=[0, 0, 4], right=[1, 0, 0], up=[0, 1, 0], forward=[0, 0, -1], tan_x=0.5, tan_y=0.375)
+    host = rt.HostScene(tri, which, mats, cam)
+    m = 50000
+    o = rng.uniform(-1.2, 1.2, size=(m, 3)).astype(np.float32)
+    d = rng.normal(size=(m, 3)).astype(np.float32)
+    for bound, order in ((None, rt.HITS_LEAF_ORDER), (None, rt.HITS_REFERENCE_ORDER), ("3", rt.HITS_LEAF_ORDER)):
+        if bound is None:
+            monkeypatch.delenv("RT_TEST_STEP_BOUND", raising=False)
+        else:
+            monkeypatch.setenv("RT_TEST_STEP_BOUND", bound)
+        with rt.Scene(host, device=0) as gpu:
+            gpu.set_hit_order(order)
+            gpu.set_counting(True)
+            for what in ("rays", "primary", "mega", "wavefront", "replay"):
+                gpu.reset_counters()
+                if what == "rays":
+                    gpu.intersect(o, d)
+                elif what == "primary":
+                    gpu.trace_primary(128, 96)
+                elif what == "replay":
+                    gpu.render(64, 48, 2, max_depth=5, rng_mode=rt.RNG_REFERENCE)
+                else:
+                    gpu.render(128, 96, 3, max_depth=6, rng_mode=rt.RNG_COUNTER, seed=2,
+                               pipeline=rt.PIPE_MEGAKERNEL if what == "mega" else rt.PIPE_WAVEFRONT)
+                if bound is None:
+                    c = gpu.counters()
+                    assert c["nodes"] > 0 and c["tri_tests"] > 0, what
+                else:
+                    with pytest.raises(rt.RtError) as ei:
+                        gpu.counters()
+                    assert ei.value.code == -1 and "step bound" in str(ei.value), what
+
+
 def test_command_line_end_to_end(scene_dir, oracle_mod, tmp_path):
     """The reference's command line (main.cpp:1244-1259): `raytracing scene W H spp out.ppm` writes the
     P6 file the CPU path would write -- same header, same bytes."""
