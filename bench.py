@@ -44,7 +44,12 @@ def main():
     ap.add_argument("--pipeline", default="wavefront", choices=["mega", "wavefront"])
     ap.add_argument("--spp", type=int, default=0, help="override the workload's samples per pixel of the whole frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--multi", type=int, default=0, metavar="N",
+                    help="single-process run only: also time the same frame through rt_multi_render (one process, N GPUs, "
+                         "RCCL reduce inside the library) and report it beside the per-process path")
     ap.add_argument("--no-primary", action="store_true")
+    ap.add_argument("--no-counting", action="store_true",
+                    help="skip the counting launch behind the timed region (profiling runs: every launch is then one of the timed ones)")
     args = ap.parse_args()
 
     # Standard output carries the one JSON line and nothing else: libraries that write to file descriptor 1
@@ -53,6 +58,14 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Every rank builds the scene's BVH with OpenMP on the host before the timed region: the ranks of one node share
+    # its cores (set before the library and its OpenMP runtime load).
+    threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), (os.cpu_count() or 16) // max(world, 1)))
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -60,9 +73,6 @@ def main():
     import raytracing_amd as rt
     from raytracing_amd import scenes
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
@@ -91,8 +101,17 @@ def main():
     seed = 0x5EED
     npix = W * H
 
-    tmp = tempfile.mkdtemp(prefix="rt_bench_%d_" % rank)
-    path = scenes.generate(gen, os.path.join(tmp, gen + ".gltf"), **gen_kw)
+    # The scene file is written once, by rank 0; the others read it after a barrier.
+    if world > 1:
+        tmp = os.path.join(tempfile.gettempdir(), "rt_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "run")))
+        if rank == 0:
+            os.makedirs(tmp, exist_ok=True)
+            scenes.generate(gen, os.path.join(tmp, gen + ".gltf"), **gen_kw)
+        dist.barrier()
+        path = os.path.join(tmp, gen + ".gltf")
+    else:
+        tmp = tempfile.mkdtemp(prefix="rt_bench_")
+        path = scenes.generate(gen, os.path.join(tmp, gen + ".gltf"), **gen_kw)
     host = rt.load_gltf(path, W, H)
     scene = rt.Scene(host, device=local_rank)
     stats = scene.stats()
@@ -144,31 +163,37 @@ def main():
         dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel -----------------------------------------------------------
-    # Dominant kernel: wf_extend (closest hit of a ray queue) for the wavefront pipeline, k_render_mega
-    # for the megakernel.  Three ceilings are priced and the one the kernel sits closest to is reported
-    # as roofline.bound / achieved / peak / frac:
-    #   vmem  the CU's vector-memory path: 64-byte L1 accesses per second (TCP_TOTAL_CACHE_ACCESSES of the
-    #         committed rocprofv3 --pmc pass / the launch time measured here) against one access per cycle and
-    #         CU at the 2.4 GHz peak clock (a pure dependent-gather microbenchmark with its table in L1,
-    #         tools/microbench/node_fetch A32, sustains 0.85 per cycle; the sorted, partly coherent rays of this
-    #         kernel get closer to one than that)
+    # ---- roofline ------------------------------------------------------------------------------------
+    # Dominant kernel: wf_extend (closest hit of a ray queue) for the wavefront pipeline, k_render_mega for the
+    # megakernel; wf_shade is priced beside it.  Per kernel three ceilings, and the one the kernel sits closest
+    # to is its bound:
+    #   vmem  the CU's vector-memory path: 64-byte L1 accesses per second (TCP_TOTAL_CACHE_ACCESSES) against one
+    #         access per cycle and CU at the 2.4 GHz peak clock; the rate a pure dependent-gather microbenchmark
+    #         sustains (tools/microbench/node_fetch, table resident in L1) is printed next to it
     #   valu  SQ_INSTS_VALU x 2 cycles (CDNA4's SIMDs are 32 lanes wide: a wave64 instruction issues over 2 cycles)
-    #         against 256 CUs x 4 SIMDs x the launch's cycles
-    #   hbm   measured L2<->fabric bytes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction) per second
-    #         against the 8 TB/s HBM peak (an upper bound on HBM proper: Infinity Cache hits are in it)
-    # The ALGORITHMIC bytes (48 B per four-child node visited, 48 B per ray/triangle test, 44 B of queue traffic
-    # per segment; visit counts from the counting build of the same kernels on the same workload, one
-    # extra launch outside the timed region) are reported beside them; they are served by L1/L2/Infinity
-    # Cache -- the 83 MB scene stays on chip -- so their rate is not bounded by HBM.
-    # Duration: HIP events recorded around every launch of that kernel on its stream during the timed steps.
-    scene.set_counting(True)
-    scene.reset_counters(stream)
+    #         against 256 CUs x 4 SIMDs x the cycles of the same launches (GRBM_GUI_ACTIVE)
+    #   hbm   L2<->fabric bytes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction) per second against the 8 TB/s
+    #         HBM peak (an upper bound on HBM proper: Infinity Cache hits are in it)
+    # Counters: the committed rocprofv3 --pmc passes of this workload (profiles/pmc_rates.json), summed over the
+    # launches of ONE wavefront pass -- the last pass of a run whose sort tuner had settled, i.e. the state the
+    # timed steps here run in -- and scaled by the ray segments of a pass; durations: HIP events recorded here
+    # around every launch on its stream, summed per pass.  Without a PMC record of the workload the ceilings stay
+    # empty and `frac` is null.
+    # The ALGORITHMIC bytes (wf_extend: 48 B per four-child node visited, 48 B per ray/triangle test, 44 B of queue
+    # traffic per segment; visit counts from the counting build of the same kernels on the same workload, one
+    # extra launch outside the timed region) are reported beside them; they are served by L1/L2/Infinity Cache --
+    # the 83 MB scene stays on chip -- so their rate is not bounded by HBM.
     count_spp = min(spp_gpu, 4)
-    scene.render_dev(W, H, count_spp, buf.data_ptr(), max_depth=depth, rng_mode=rt.RNG_COUNTER, seed=seed,
-                     spp_begin=0, pipeline=pipeline, stream=stream)
-    c = scene.counters()
-    scene.set_counting(False)
+    if args.no_counting:   # visits per segment unknown: priced as zero below
+        c = {"nodes": 0, "tri_tests": 0, "light_tests": 0, "segments": segs / float(args.steps), "node_lane_slots": 0, "tri_lane_slots": 0}
+        count_spp = spp_gpu
+    else:
+        scene.set_counting(True)
+        scene.reset_counters(stream)
+        scene.render_dev(W, H, count_spp, buf.data_ptr(), max_depth=depth, rng_mode=rt.RNG_COUNTER, seed=seed,
+                         spp_begin=0, pipeline=pipeline, stream=stream)
+        c = scene.counters()
+        scene.set_counting(False)
     n_node = c["nodes"] / c["segments"]
     n_tri = c["tri_tests"] / c["segments"]
     n_light = c["light_tests"] / c["segments"]
@@ -176,55 +201,90 @@ def main():
     if pipeline == rt.PIPE_MEGAKERNEL:
         kname, kind = "k_render_mega", "mega"
         bytes_per_seg = 32.0 * n_node + 48.0 * n_tri + 32.0 + 64.0 * n_light
+        passes = max(ktimes["mega"][1], 1)
     else:
         kname, kind = "wf_extend", "extend"
         # wf_extend walks the four-child tree (48-byte nodes) unless RT_WF_WIDE=0 (32-byte two-child nodes);
         # per segment it also reads a 4-byte queue entry and the 32-byte ray and writes the 8-byte hit
         node_bytes = 32.0 if os.environ.get("RT_WF_WIDE") == "0" else 48.0
         bytes_per_seg = node_bytes * n_node + 48.0 * n_tri + 44.0
+        passes = max(ktimes["generate"][1], 1)          # one wf_generate per pass of up to 128 frames of samples
     k_ms, k_launches = ktimes[kind]
     launch_ms = k_ms / max(k_launches, 1)
     launch_s = launch_ms * 1e-3
     segs_per_launch = segs / float(max(k_launches, 1))
+    segs_per_pass = segs / float(passes)
     algorithmic = segs_per_launch * bytes_per_seg / launch_s / 1e9
-    ceilings, traffic, pmc_src = {}, None, None
+    # wf_shade, per path vertex (= per segment: every traced ray is shaded once): 4 B queue entry + 8 B hit + 48 B
+    # record read, 32 B of the hit triangle gathered, 52 B written for the paths that go on (all but one vertex per sample)
+    shade_bytes = 60.0 + 32.0 + 52.0 * (1.0 - 1.0 / seg_per_sample)
+
+    def ceilings_of(rec, scale, seconds):
+        out = {}
+        if rec.get("fabric_bytes"):
+            out["hbm"] = {"achieved": round(rec["fabric_bytes"] * scale / seconds / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        if "l1_accesses" in rec:
+            out["vmem"] = {"achieved": round(rec["l1_accesses"] * scale / seconds / 1e9, 1), "peak": round(256 * 2.4, 1),
+                           "unit": "G L1 accesses/s", "peak_source": "theoretical: 256 CUs x 2.4 GHz x one 64-byte L1 access per cycle"}
+        if "valu_wave_insts" in rec and "gui_active_cycles_sum_xcd" in rec:
+            cycles = rec["gui_active_cycles_sum_xcd"] / 8.0     # the counter sums the 8 XCDs
+            out["valu"] = {"achieved": round(rec["valu_wave_insts"] * 2.0 / cycles, 1), "peak": 256 * 4.0,
+                           "unit": "busy SIMDs (wave64 VALU instruction = 2 cycles on a SIMD-32; instructions and cycles of the same PMC launches)"}
+        for v in out.values():
+            v["frac"] = round(v["achieved"] / v["peak"], 4)
+        return out
+
+    kernels, traffic, pmc_src, gather = {}, None, None, None
     rpath = os.path.join(ROOT, "profiles", "pmc_rates.json")
     if os.path.exists(rpath):
         rates = json.load(open(rpath))
-        rec = rates["kernels"].get(kname) if rates.get("workload") == args.workload else None
-        if rec:
-            pmc_src = rates["source"]
-            # the counters are per launch of the PMC pass: scale them to this run's launch size
-            scale = segs_per_launch / rates["segments_per_launch"] if rates.get("segments_per_launch") else 1.0
-            rec = {k: (v * scale if k != "launches" else v) for k, v in rec.items()}
-            traffic = rec.get("fabric_bytes")
-            if traffic:
-                ceilings["hbm"] = {"achieved": round(traffic / launch_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        settled = rates.get("settled", {}).get("kernels", {}) if rates.get("workload") == args.workload else {}
+        if settled and rates.get("segments_per_pass"):
+            pmc_src = rates["source"] + " (last pass of the run: sort tuner settled)"
+            scale = segs_per_pass / rates["segments_per_pass"]
             peak = rates.get("vmem_gather_peak")
-            if "l1_accesses" in rec:
-                ceilings["vmem"] = {"achieved": round(rec["l1_accesses"] / launch_s / 1e9, 1),
-                                    "peak": round(256 * 2.4, 1), "unit": "G L1 accesses/s",
-                                    "peak_source": "256 CUs x 2.4 GHz x one 64-byte L1 access per cycle",
-                                    "gather_microbenchmark": round(peak["lane_loads_per_s"] / 1e9, 1) if peak else None}
-            if "valu_wave_insts" in rec and "gui_active_cycles_sum_xcd" in rec:
-                cycles = rec["gui_active_cycles_sum_xcd"] / 8.0     # the counter sums the 8 XCDs
-                ceilings["valu"] = {"achieved": round(rec["valu_wave_insts"] * 2.0 / cycles, 1), "peak": 256 * 4.0,
-                                    "unit": "busy SIMDs (wave64 VALU instruction = 2 cycles on a SIMD-32; cycles from the PMC pass)"}
-    for v in ceilings.values():
-        v["frac"] = round(v["achieved"] / v["peak"], 4)
-    if ceilings:
-        bound = max(ceilings, key=lambda k: ceilings[k]["frac"])
-        top = ceilings[bound]
-    else:   # no committed PMC pass for this workload: only the algorithmic rate is known
-        bound, top = "hbm", {"achieved": round(algorithmic, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(algorithmic / HBM_PEAK_GBS, 5)}
-    roofline = {"bound": bound, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
-                "traffic": traffic, "ceilings": ceilings, "pmc_source": pmc_src,
-                "kernel": kname, "launch_ms": round(launch_ms, 4), "launches": k_launches,
+            gather = round(peak["lane_loads_per_s"] / 1e9, 1) if peak else None
+            for kn, kd, alg_bytes in ((kname, kind, bytes_per_seg), ("wf_shade", "shade", shade_bytes)):
+                rec = settled.get(kn)
+                if not rec or not ktimes[kd][1]:
+                    continue
+                pass_s = ktimes[kd][0] / passes * 1e-3
+                ce = ceilings_of(rec, scale, pass_s)
+                if "vmem" in ce and gather:
+                    ce["vmem"]["measured_gather_peak"] = gather
+                    ce["vmem"]["frac_of_measured_gather_peak"] = round(ce["vmem"]["achieved"] / gather, 4)
+                bnd = max(ce, key=lambda k: ce[k]["frac"]) if ce else None
+                kernels[kn] = {"bound": bnd, "frac": ce[bnd]["frac"] if bnd else None, "ceilings": ce,
+                               "ms_per_pass": round(pass_s * 1e3, 3), "pmc_ms_per_pass": round(rec.get("duration_ms", 0.0), 3),
+                               "traffic_per_pass": round(rec["fabric_bytes"] * scale) if rec.get("fabric_bytes") else None,
+                               "algorithmic_bytes_per_segment": round(alg_bytes, 1),
+                               "algorithmic_GB/s": round(segs_per_pass * alg_bytes / pass_s / 1e9, 1),
+                               "l1_accesses_per_segment": round(rec["l1_accesses"] / rates["segments_per_pass"], 2) if "l1_accesses" in rec else None,
+                               "l2_misses_per_segment": round(rec["l2_misses"] / rates["segments_per_pass"], 3) if "l2_misses" in rec else None}
+            if kname in kernels and kernels[kname]["traffic_per_pass"]:
+                traffic = kernels[kname]["traffic_per_pass"] * passes / float(max(k_launches, 1))    # per launch, like `achieved`
+    dom = kernels.get(kname)
+    if dom and dom["bound"]:
+        top = dom["ceilings"][dom["bound"]]
+        bound, achieved, peak_v, unit, frac = dom["bound"], top["achieved"], top["peak"], top["unit"], top["frac"]
+    else:   # no committed PMC pass for this workload: only the algorithmic rate is known, which is not an HBM rate
+        bound, achieved, peak_v, unit, frac = "hbm", None, HBM_PEAK_GBS, "GB/s", None
+    model = None
+    mpath = os.path.join(ROOT, "profiles", "r03_bvh_sim.json")
+    if args.workload == "spheres1m" and os.path.exists(mpath):
+        m = json.load(open(mpath))
+        tree = m["four_child_tree_8bit_boxes" if pipeline == rt.PIPE_WAVEFRONT and os.environ.get("RT_WF_WIDE") != "0" else "two_child_tree"]
+        model = {"source": "profiles/r03_bvh_sim.json: " + m["tool"],
+                 "per_bounce": [{"bounce": r["bounce"], "nodes": r["nodes_per_ray"], "tri_tests": r["tri_tests_per_ray"]} for r in tree]}
+    roofline = {"bound": bound, "achieved": achieved, "peak": peak_v, "unit": unit, "frac": frac,
+                "traffic": traffic, "pmc_source": pmc_src, "kernel": kname, "kernels": kernels,
+                "launch_ms": round(launch_ms, 4), "launches": k_launches, "passes": passes,
+                "segments_per_pass": round(segs_per_pass, 1),
                 "algorithmic": {"GB/s": round(algorithmic, 1), "of_hbm_peak": round(algorithmic / HBM_PEAK_GBS, 4),
                                 "bytes_per_segment": round(bytes_per_seg, 1), "segments_per_launch": round(segs_per_launch, 1),
                                 "served_by": "L1 / L2 / Infinity Cache (the scene stays on chip): not an HBM rate"},
                 "nodes_per_segment": round(n_node, 2), "tri_tests_per_segment": round(n_tri, 2),
+                "cpu_model_of_the_walk": model,
                 "light_tests_per_segment": round(n_light, 2), "segments_per_sample": round(seg_per_sample, 3),
                 "lane_occupancy": {"node_phase": round(c["nodes"] / max(c["node_lane_slots"], 1), 3),
                                    "triangle_phase": round(c["tri_tests"] / max(c["tri_lane_slots"], 1), 3)},
@@ -270,6 +330,23 @@ def main():
                          % (cw, ch, cspp, build_s)}
         orc.close()
 
+    # ---- the same frame through the one-process entry point (rt_multi_*: one host BVH build, RCCL inside) --------
+    if args.multi > 0 and world == 1:
+        scene.close()
+        with rt.MultiScene(host, list(range(args.multi))) as multi:
+            frame = None
+            for _ in range(max(args.warmup, 1)):
+                frame = multi.render(W, H, spp_total, max_depth=depth, seed=seed, pipeline=pipeline)
+            tb = time.perf_counter()
+            for _ in range(args.steps):
+                frame = multi.render(W, H, spp_total, max_depth=depth, seed=seed, pipeline=pipeline)
+            multi_s = (time.perf_counter() - tb) / args.steps
+            msegs = sum(multi.scene(g).counters()["segments"] for g in range(multi.ndev)) / float(max(args.warmup, 1) + args.steps)
+            extra["multi_one_process"] = {
+                "n_gpus": multi.ndev, "ms_per_frame": round(multi_s * 1e3, 3), "Mrays_per_s": round(msegs / multi_s * 1e-6, 1),
+                "note": "rt_multi_render: samples split over the GPUs, one ncclReduce, result copied to the host (included); "
+                        "no tone mapping in the timed region"}
+
     value = total_segs / elapsed * 1e-6
     out = {
         "metric": "Mrays/s (all bounces)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
@@ -288,7 +365,8 @@ def main():
     sys.stdout.flush()
     os.write(result_fd, (json.dumps(out) + "\n").encode())
     os.close(result_fd)
-    scene.close()
+    if not (args.multi > 0 and world == 1):
+        scene.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -3,13 +3,16 @@
 // trees collapsed from it under different stack budgets.  Host only (no GPU call).
 //
 //   g++ -O2 -fopenmp -std=gnu++17 -I include tools/bvh_sim.cpp -o /tmp/bvh_sim -L raytracing_amd/lib -lrt_amd -Wl,-rpath,$PWD/raytracing_amd/lib
-//   /tmp/bvh_sim scene.gltf [rays per bounce, default 200000]
+//   /tmp/bvh_sim scene.gltf [rays per bounce, default 200000] [summary.json]
+// summary.json: the per-bounce counts of the two-child tree and of the four-child tree with 8-bit boxes (the two
+// the kernels walk), for bench.py to print beside the device's own counts.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <string>
 #include <vector>
 
 #include "rt_amd.h"
@@ -305,8 +308,10 @@ int main(int argc, char **argv) {
         }
     }
 
-    auto report = [&](const char *name, bool wide) {
+    std::string json;
+    auto report = [&](const char *name, bool wide, const char *key = nullptr) {
         printf("%-34s", name);
+        if (key) json += std::string(json.empty() ? "" : ", ") + "\"" + key + "\": [";
         for (int b = 0; b < 4; ++b) {
             Counts c;
             long mism = 0;
@@ -318,10 +323,17 @@ int main(int argc, char **argv) {
             }
             double n = (double)gen[b].size();
             printf(" | b%d: %5.1f nodes %5.1f boxes %4.1f tris sp %ld", b, c.nodes / n, c.boxes / n, c.tris / n, c.maxsp);
+            if (key) {
+                char buf[160];
+                snprintf(buf, sizeof buf, "%s{\"bounce\": %d, \"rays\": %zu, \"nodes_per_ray\": %.3f, \"tri_tests_per_ray\": %.3f}", b ? ", " : "", b,
+                         gen[b].size(), c.nodes / n, c.tris / n);
+                json += buf;
+            }
         }
+        if (key) json += "]";
         printf("\n");
     };
-    report("two-child tree", false);
+    report("two-child tree", false, "two_child_tree");
     struct Cfg { const char *name; int mode, low, budget, arity, order, qbits; };
     const Cfg cfgs[] = {
         {"4-wide, no stack bound", 0, 0, 1000, 4},
@@ -348,7 +360,15 @@ int main(int argc, char **argv) {
         for (const WNode &w : g_wide) fill += w.n;
         char nm[128];
         snprintf(nm, sizeof nm, "%s (%zu nodes, fill %.2f, need %ld)", cf.name, g_wide.size(), fill / g_wide.size(), g_stackNeedMax);
-        report(nm, true);
+        report(nm, true, cf.qbits == 8 ? "four_child_tree_8bit_boxes" : nullptr);
+    }
+    if (argc > 3) {
+        FILE *f = fopen(argv[3], "w");
+        if (f) {
+            fprintf(f, "{\"tool\": \"tools/bvh_sim.cpp: CPU model of the walk over the flattened tree (camera rays, then cosine-distributed bounces; leaves tested when reached)\", "
+                       "\"nodes\": %u, \"triangle_records\": %u, %s}\n", info[0], info[1], json.c_str());
+            fclose(f);
+        }
     }
     rt_flat_free(flat);
     rt_host_scene_free(hs);
