@@ -120,10 +120,14 @@ typedef struct rt_material {
 /* Analytic primitives: Primitive + Plane / Ellipsoid / Box (main.cpp:199-464).  The reference's loader
  * never constructs them (it emits triangles only, main.cpp:1089), so scene files cannot describe them;
  * they enter through rt_scene_desc.  Their intersectPrimitive arithmetic is reproduced; they are shaded
- * like triangles with the material they name, which must not emit (the light list, main.cpp:1096-1098,
- * holds triangles only here: sampling and pdf of emissive analytic primitives are not built).  In the
- * closest-hit results primitive k has id ntri + k.  At most RT_MAX_PRIMITIVES per scene: they are tested one
- * by one after the walk through the triangle tree, as the reference tests planes at its root (552-558). */
+ * like triangles with the material they name.  An ellipsoid or box whose material emits joins the light list
+ * (main.cpp:1096-1098) behind the light triangles, in list order: LightSurface samples it (Ellipsoid /
+ * Box::samplePoint, main.cpp:320-330, 425-441) and adds its density (Ellipsoid / Box::pdf through
+ * Primitive::intersectFull / pdfFull, main.cpp:218-239, 332-356, 443-455), as written in the reference, its
+ * oddities included.  A plane must not emit (Plane::samplePoint throws, main.cpp:261-267).  In the closest-hit
+ * results primitive k has id ntri + k.  At most RT_MAX_PRIMITIVES per scene.  Under RT_HITS_LEAF_ORDER they are
+ * tested one by one after the walk through the triangle tree; under RT_HITS_REFERENCE_ORDER they sit where
+ * BVH::build puts them: planes at the root, the others in the tree under their calculateAABB boxes (552-558). */
 #define RT_PRIM_PLANE 0     /* param = normal (local space; need not be unit length), main.cpp:242-276 */
 #define RT_PRIM_ELLIPSOID 1 /* param = radius per axis, main.cpp:278-365 */
 #define RT_PRIM_BOX 2       /* param = half extent per axis ("size" as intersectPrimitive uses it, 374-375) */
@@ -159,7 +163,7 @@ typedef struct rt_host_scene rt_host_scene; /* parsed scene file, host memory on
 
 typedef struct rt_scene_stats {
     uint32_t ntri;
-    uint32_t nlights;
+    uint32_t nlights;     /* light triangles + emissive analytic primitives */
     uint32_t nnodes;      /* 32-byte two-child nodes (the four-child tree wf_extend walks has about half as many) */
     uint32_t tree_height; /* inner-node levels on the longest root-to-leaf path */
     double build_seconds; /* host BVH build + flatten */

@@ -36,6 +36,7 @@
 #include <cstdint>
 #include <cstring>
 #include <random>
+#include <utility>
 #include <vector>
 
 #include <omp.h>
@@ -310,6 +311,68 @@ struct Analytic {
         }
     }
 
+    // Primitive::intersectFull, main.cpp:218-230
+    std::pair<Intersection, Intersection> intersectFull(vec3 o, vec3 d, int32_t self) const {
+        Intersection i1 = intersectPrimitive(o, d, self);
+        if (!i1.isIntersected) return {i1, i1};
+        Intersection i2;
+        if (i1.isInside) i2 = intersectPrimitive(i1.pPlusNormalEps, -d, self);
+        else i2 = intersectPrimitive(i1.pMinusNormalEps, d, self);
+        return {i1, i2};
+    }
+    // Primitive::pdfFull, main.cpp:232-239
+    static float pdfFull(vec3 o, const Intersection &i1, const Intersection &i2, float p1, float p2) {
+        vec3 r1 = i1.p - o;
+        vec3 r2 = i2.p - o;
+        float fp1 = p1 * dot(r1, r1) / std::fabs(dot(normalize(r1), i1.normal));
+        float fp2 = p2 * dot(r2, r2) / std::fabs(dot(normalize(r2), i2.normal));
+        return fp1 + fp2;
+    }
+    // Ellipsoid::samplePoint (main.cpp:320-330), Box::samplePoint (425-441); Plane::samplePoint throws (261-263)
+    vec3 samplePoint(Rng &rng) const {
+        if (type == PRIM_ELLIPSOID) {
+            float x = sampleNormal(rng);
+            float y = sampleNormal(rng);
+            float z = sampleNormal(rng);
+            vec3 point = normalize(V(x, y, z));
+            point.x *= param.x;
+            point.y *= param.y;
+            point.z *= param.z;
+            return rotation * point + position;
+        }
+        float wx = param.y * param.z;
+        float wy = param.x * param.z;
+        float wz = param.x * param.y;
+        float u = sampleUniform(rng, 0.f, wx + wy + wz);
+        float side = 2 * (float(sampleUniform(rng) < 0.5f) - 0.5f);
+        float c1 = sampleUniform(rng, 0.f, 2.f) - 1.f, c2 = sampleUniform(rng, 0.f, 2.f) - 1.f;
+        vec3 point;
+        if (u < wx) point = V(side * param.x, c1 * param.y, c2 * param.z);
+        else if (u < wx + wy) point = V(c1 * param.x, side * param.y, c2 * param.z);
+        else point = V(c1 * param.x, c2 * param.y, side * param.z);
+        return rotation * point + position;
+    }
+    // Ellipsoid::pdf (main.cpp:332-356: pos2 is computed from i1.p like pos1, as written there), Box::pdf (443-455)
+    float pdf(vec3 o, vec3 d, int32_t self) const {
+        std::pair<Intersection, Intersection> is = intersectFull(o, d, self);
+        const Intersection &i1 = is.first, &i2 = is.second;
+        if (!i1.isIntersected) return 0.f;
+        if (type == PRIM_ELLIPSOID) {
+            float rs = param.x * param.y * param.z;
+            rs = rs * rs;
+            float rxs = param.x * param.x;
+            float rys = param.y * param.y;
+            float rzs = param.z * param.z;
+            vec3 pos1 = conjRotation * (i1.p - position);
+            vec3 pos2 = conjRotation * (i1.p - position);
+            float p1 = ONE_OVER_PI / 4.f / std::sqrt(pos1.x * pos1.x * rs / rxs + pos1.y * pos1.y * rs / rys + pos1.z * pos1.z * rs / rzs);
+            float p2 = ONE_OVER_PI / 4.f / std::sqrt(pos2.x * pos2.x * rs / rxs + pos2.y * pos2.y * rs / rys + pos2.z * pos2.z * rs / rzs);
+            return pdfFull(o, i1, i2, p1, p2);
+        }
+        float p = 1.f / 8.f / (param.y * param.z + param.x * param.z + param.x * param.y);
+        return pdfFull(o, i1, i2, p, p);
+    }
+
     Intersection intersectPrimitive(vec3 o, vec3 d, int32_t self) const {
         vec3 no = conjRotation * (o - position);
         vec3 nd = conjRotation * d;
@@ -407,7 +470,8 @@ struct Item {
 
 struct Scene {  // main.cpp:689-706 (InputData), minus width/height/samples which are call arguments
     std::vector<Triangle> tris;    // loader order
-    std::vector<int32_t> lights;   // loader-order ids of the emissive triangles, in emission order (main.cpp:1096-1098)
+    std::vector<int32_t> lights;   // the emissive primitives (main.cpp:1096-1098): loader-order triangle ids in emission
+                                   // order, then -2 - k for every emissive analytic primitive k in list order
     std::vector<Material> mats;
     std::vector<Analytic> prims;   // Intersection::primitive of analytic primitive k is -2 - k
     bool primsInTree = false;      // analytic primitives placed by BVH::build (true) or folded in after the walk
@@ -417,6 +481,12 @@ struct Scene {  // main.cpp:689-706 (InputData), minus width/height/samples whic
     // material of whatever an Intersection names
     const Material &materialOf(int32_t primitive) const {
         return mats[primitive >= 0 ? tris[primitive].material : prims[-2 - primitive].material];
+    }
+    vec3 samplePointOf(int32_t primitive, Rng &rng) const {
+        return primitive >= 0 ? tris[primitive].samplePoint(rng) : prims[-2 - primitive].samplePoint(rng);
+    }
+    float pdfOf(int32_t primitive, vec3 o, vec3 d) const {
+        return primitive >= 0 ? tris[primitive].pdf(o, d, primitive) : prims[-2 - primitive].pdf(o, d, primitive);
     }
     Intersection intersectItem(const Item &it, vec3 o, vec3 d) const {
         return it.prim >= 0 ? tris[it.prim].intersectPrimitive(o, d, it.prim)
@@ -630,14 +700,14 @@ inline float cosinePdf(vec3 n, vec3 d) {  // main.cpp:748-754
 inline vec3 lightSample(const Scene &s, vec3 x, Rng &rng) {  // main.cpp:764-769
     if (s.lights.empty()) return V(0.f, 0.f, 0.f);
     uint16_t k = sampleUInt(rng, 0, (uint16_t)(s.lights.size() - 1));
-    return normalize(s.tris[s.lights[k]].samplePoint(rng) - x);
+    return normalize(s.samplePointOf(s.lights[k], rng) - x);
 }
 inline float lightPdf(const Scene &s, vec3 x, vec3 d, int32_t primitive, Counters &c) {  // 771-783
     float ps = 0.f;
     for (int32_t light : s.lights) {
         if (light == primitive) continue;
         ++c.light_tests;
-        ps += s.tris[light].pdf(x, d, light);
+        ps += s.pdfOf(light, x, d);
     }
     if (ps < EPS || std::isnan(ps) || std::isinf(ps)) return 0.f;
     return ps / float(s.lights.size());
@@ -1028,6 +1098,10 @@ void orc_scene_set_primitives(void *h, const orc_primitive *p, uint32_t n, int i
     }
     s->primsInTree = in_tree != 0;
     buildScene(*s);
+    // the light list (main.cpp:1096-1098): the emissive triangles as before, then the emissive analytic primitives
+    while (!s->lights.empty() && s->lights.back() < 0) s->lights.pop_back();
+    for (uint32_t k = 0; k < n; ++k)
+        if (length(s->mats[s->prims[k].material].emission) > EPS) s->lights.push_back(-2 - (int32_t)k);
 }
 
 // Known-answer probe of the RNG layer (main.cpp:98-111), each group from a freshly seeded engine.
@@ -1091,11 +1165,12 @@ void orc_triangle_derived(void *h, float *out4) {
     }
 }
 
-// Light list in the reference's order (loader-order triangle ids).
+// Light list in the reference's order (loader-order triangle ids; ntri + k for analytic primitive k).
 uint32_t orc_lights(void *h, uint32_t *out, uint32_t cap) {
     Scene *s = asScene(h);
     uint32_t n = (uint32_t)s->lights.size();
-    for (uint32_t i = 0; i < n && i < cap; ++i) out[i] = (uint32_t)s->lights[i];
+    for (uint32_t i = 0; i < n && i < cap; ++i)
+        out[i] = s->lights[i] >= 0 ? (uint32_t)s->lights[i] : (uint32_t)s->tris.size() + (uint32_t)(-2 - s->lights[i]);
     return n;
 }
 

@@ -176,7 +176,7 @@ class OracleScene:
         return out
 
     def lights(self):
-        out = np.empty(max(self.ntri, 1), dtype=np.uint32)
+        out = np.empty(max(self.ntri + self.nprims, 1), dtype=np.uint32)
         n = lib().orc_lights(self._h, _p(out), out.shape[0])
         return out[:n].copy()
 

@@ -110,7 +110,8 @@ def node_boxes(nodes, grid):
 
 def build_flat(host_scene):
     """Host-only acceleration-structure build (no GPU): returns dict(nodes (n,8) u32, grid (6,) f32,
-    tris (m,16) f32, lights (k,) u32 leaf-order positions, height, wide (w,12) u32 four-child nodes,
+    tris (m,16) f32, lights (k,) u32 record indices (leaf-order positions of the light triangles, then m + j for
+    emissive analytic primitive j), height, wide (w,12) u32 four-child nodes,
     light_tree=dict(nodes, grid, recs (k,16), height))."""
     if isinstance(host_scene, dict):
         host_scene = HostScene(**host_scene)
@@ -130,8 +131,9 @@ def build_flat(host_scene):
         check(L.rt_flat_get_light_tree(h, _p(linfo), None, None, None))
         lgrid = np.empty(6, dtype=np.float32)
         lnodes = np.empty((int(linfo[0]), 8), dtype=np.uint32)
-        lrecs = np.empty((lights.size, 16), dtype=np.float32)
-        check(L.rt_flat_get_light_tree(h, None, _p(lgrid), _p(lnodes), _p(lrecs) if lights.size else None))
+        ntl = int((lights < tris.shape[0]).sum())      # the light triangles lead the list; emissive analytic primitives follow
+        lrecs = np.empty((ntl, 16), dtype=np.float32)
+        check(L.rt_flat_get_light_tree(h, None, _p(lgrid), _p(lnodes), _p(lrecs) if ntl else None))
         capped, sah_n, sah_t = C.c_uint32(), C.c_double(), C.c_double()
         check(L.rt_flat_get_quality(h, C.byref(capped), C.byref(sah_n), C.byref(sah_t)))
         rinfo = np.zeros(4, dtype=np.uint32)

@@ -517,8 +517,8 @@ void build_flat_scene(const rt_scene_desc &desc, FlatScene &out) {
             throw std::runtime_error("analytic primitive type must be RT_PRIM_PLANE, _ELLIPSOID or _BOX");
         if (p.material >= desc.nmat) throw std::runtime_error("analytic primitive names a missing material");
         const rt_material &m = desc.materials[p.material];
-        if (hm::length(hm::V3(m.emission[0], m.emission[1], m.emission[2])) > EPS)
-            throw std::runtime_error("analytic primitives must not emit: lights are triangles");
+        if (p.type == RT_PRIM_PLANE && hm::length(hm::V3(m.emission[0], m.emission[1], m.emission[2])) > EPS)
+            throw std::runtime_error("a plane must not emit: it cannot be sampled (Plane::samplePoint throws, main.cpp:261-267)");
         float q2 = 0.f, n2 = 0.f;
         for (int a = 0; a < 4; ++a) {
             if (!std::isfinite(p.rotation[a])) throw std::runtime_error("non-finite primitive rotation");
@@ -590,6 +590,12 @@ void build_flat_scene(const rt_scene_desc &desc, FlatScene &out) {
             out.lights.push_back(posOfId[id]);
             lightIds.push_back(id);
         }
+    }
+    out.ntrilights = (uint32_t)out.lights.size();
+    // ... then the emissive analytic primitives in list order, as record indices behind the triangle records
+    for (uint32_t k = 0; k < desc.nprim; ++k) {
+        const rt_material &m = desc.materials[desc.prims[k].material];
+        if (hm::length(hm::V3(m.emission[0], m.emission[1], m.emission[2])) > EPS) out.lights.push_back(nslots + k);
     }
 
     // A second tree over the light triangles alone, for LightSurface::pdf (main.cpp:771-783) when the
@@ -686,7 +692,7 @@ int rt_flat_get_light_tree(const rt_flat *f, uint32_t info[2], float grid[6], ui
             grid[3 + a] = s.light_grid_cell[a];
         }
     if (nodes) std::memcpy(nodes, s.light_nodes.data(), (size_t)s.light_nnodes * 8 * sizeof(uint32_t));
-    if (recs) std::memcpy(recs, s.light_recs.data(), s.lights.size() * 16 * sizeof(float));
+    if (recs) std::memcpy(recs, s.light_recs.data(), (size_t)s.ntrilights * 16 * sizeof(float));
     return RT_OK;
 }
 

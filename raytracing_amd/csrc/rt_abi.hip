@@ -338,7 +338,7 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
         // 60: 48.3 vs 43.4, 240: 108 vs 54, 960: 321 vs 65 (loop vs tree).
         const char *e = std::getenv("RT_LIGHT_TREE_MIN");
         const long minLights = e ? std::atol(e) : 48;
-        v.light_tree = (long)f.lights.size() >= minLights && !f.lights.empty() ? std::max<uint32_t>(f.light_height, 1u) : 0u;
+        v.light_tree = (long)f.ntrilights >= minLights && f.ntrilights ? std::max<uint32_t>(f.light_height, 1u) : 0u;
         // wf_shade has an instantiation with a short stack for light trees of at most 16 levels;
         // RT_LIGHT_STACK_FULL=1 (tests) reports a deep tree and so selects the general one
         if (v.light_tree && std::getenv("RT_LIGHT_STACK_FULL")) v.light_tree = std::max<uint32_t>(v.light_tree, rtd::kStack);
@@ -360,6 +360,7 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
     v.nprims = f.nprims;
     v.counters = s->d_counters;
     v.nlights = (uint32_t)f.lights.size();
+    v.ntrilights = f.ntrilights;
     v.nmats = (uint32_t)mats.size();
     for (int k = 0; k < 3; ++k) {
         v.grid_origin[k] = f.grid_origin[k];

@@ -120,13 +120,15 @@ struct DevScene {
     const float4 *tris;       // 4 x float4 per triangle, leaf order
     const uint4 *lnodes;      // tree over the light triangles only (same node format, own grid)
     const float4 *lrecs;      // 4 x float4 per light in that tree's leaf order; q3 = (bits(light index), bits(leaf position), pdfConst, 0)
-    const uint32_t *lights;   // leaf-order positions of the emissive triangles
+    const uint32_t *lights;   // the light list as record indices: the emissive triangles (leaf-order positions), then ntri + k for
+                              // every emissive analytic primitive k
     const DevMaterial *mats;
     const float4 *prims;      // 3 x float4 per analytic primitive: (position.xyz, bits(type)), rotation xyzw, (param.xyz, bits(material))
     const float4 *rnodes;     // 4 x float4 per node of the tree the reference itself would build (ref_closest_hit); null when the scene is beyond its limits
     const uint32_t *ritems;   // the reference's re-ordered primitive list as record indices (triangle record, or ntri + k)
     unsigned long long *counters;  // kCounterShards x kCounterStride; per shard [0] segments [1] nodes [2] tri tests [3] light tests
-    uint32_t nlights, nmats;
+    uint32_t nlights, nmats;             // nlights: all lights; the first ntrilights of them are triangles
+    uint32_t ntrilights;
     uint32_t ntri, nprims;               // ntri = triangle RECORDS (pads included): a hit index >= ntri names analytic primitive (index - ntri)
     uint32_t npad;                       // pad records among them: the caller sees primitive k as (loader triangle count) + k
     uint32_t light_tree;                 // nonzero: the launchers pick the kernels whose light_pdf walks lnodes; the value is that tree's height
@@ -873,7 +875,7 @@ struct LightCacheStorage {
 
 // Call from all threads of the workgroup; ends with a barrier.
 __device__ __forceinline__ LightCache load_light_cache(const DevScene &S, LightCacheStorage &st, int *lane_stack) {
-    const uint32_t n = S.nlights < kLdsLights ? S.nlights : kLdsLights;
+    const uint32_t n = S.ntrilights < kLdsLights ? S.ntrilights : kLdsLights;
     const uint32_t nm = S.nmats < kLdsMats ? S.nmats : kLdsMats;
     for (uint32_t e = threadIdx.x; e < 4u * n; e += kBlock) st.recs[e] = S.tris[4 * (size_t)S.lights[e >> 2] + (e & 3u)];
     for (uint32_t e = threadIdx.x; e < 2u * nm; e += kBlock) st.mats[e] = reinterpret_cast<const float4 *>(S.mats)[e];
@@ -897,6 +899,94 @@ __device__ __forceinline__ LightCache load_light_cache(const DevScene &S, LightC
 __device__ __forceinline__ DevMaterial material(const DevScene &S, const LightCache &LC, uint32_t m) {
     if (m < LC.nm) return DevMaterial{LC.mats[2 * m], LC.mats[2 * m + 1]};
     return S.mats[m];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Emissive analytic primitives (Ellipsoid, Box): samplePoint and pdf, with Primitive::intersectFull / pdfFull
+// (main.cpp:218-239, 320-356, 425-455), operation for operation -- including what is odd about them: the
+// ellipsoid's second density is computed from the FIRST intersection point (main.cpp:347-348), and a second
+// intersection that is missed contributes through its default point (0, 0, 0) and zero normal (a division by
+// zero: the sum is then inf or NaN and LightSurface::pdf returns 0, main.cpp:779-781).
+// ---------------------------------------------------------------------------------------------
+struct FullHit {  // the fields of Intersection that pdfFull and intersectFull read
+    bool hit, inside;
+    v3 p, normal, pPlus, pMinus;
+};
+__device__ __forceinline__ FullHit full_intersect(const float4 *rec, v3 o, v3 d) {
+    const PrimHit h = prim_intersect<true>(rec, o, d);
+    FullHit f;
+    f.hit = h.hit;
+    f.inside = h.inside;
+    f.p = mk(0.f, 0.f, 0.f);
+    f.normal = mk(0.f, 0.f, 0.f);
+    f.pPlus = f.p;
+    f.pMinus = f.p;
+    if (h.hit) {  // Intersection::update, main.cpp:84-95
+        f.normal = h.normal;
+        f.p = o + h.t * d;
+        const v3 nEps = h.normal * kEps;
+        f.pPlus = f.p + nEps;
+        f.pMinus = f.p - nEps;
+    }
+    return f;
+}
+__device__ __forceinline__ float analytic_light_pdf(const float4 *rec, v3 o, v3 d) {
+    const FullHit i1 = full_intersect(rec, o, d);
+    if (!i1.hit) return 0.f;
+    const FullHit i2 = i1.inside ? full_intersect(rec, i1.pPlus, -d) : full_intersect(rec, i1.pMinus, d);
+    const float4 q0 = rec[0], rot = rec[1], q2 = rec[2];
+    const v3 par = mk(q2.x, q2.y, q2.z);
+    float p1, p2;
+    if (__float_as_int(q0.w) == 1) {  // Ellipsoid::pdf
+        float rs = par.x * par.y * par.z;
+        rs = rs * rs;
+        const float rxs = par.x * par.x, rys = par.y * par.y, rzs = par.z * par.z;
+        const float4 conj = make_float4(-rot.x, -rot.y, -rot.z, rot.w);
+        const v3 pos1 = quat_rotate(conj, i1.p - mk(q0.x, q0.y, q0.z));
+        p1 = kOneOverPi / 4.f / __builtin_sqrtf(pos1.x * pos1.x * rs / rxs + pos1.y * pos1.y * rs / rys + pos1.z * pos1.z * rs / rzs);
+        p2 = p1;  // pos2 = pos1, as the reference computes it
+    } else {  // Box::pdf
+        p1 = 1.f / 8.f / (par.y * par.z + par.x * par.z + par.x * par.y);
+        p2 = p1;
+    }
+    const v3 r1 = i1.p - o, r2 = i2.p - o;  // Primitive::pdfFull
+    const float fp1 = p1 * dot(r1, r1) / __builtin_fabsf(dot(normalize(r1), i1.normal));
+    const float fp2 = p2 * dot(r2, r2) / __builtin_fabsf(dot(normalize(r2), i2.normal));
+    return fp1 + fp2;
+}
+// Ellipsoid::samplePoint (3 normals) / Box::samplePoint (4 uniforms)
+__device__ __forceinline__ v3 analytic_sample_point(const float4 *rec, uint32_t &rng) {
+    const float4 q0 = rec[0], rot = rec[1], q2 = rec[2];
+    const v3 par = mk(q2.x, q2.y, q2.z);
+    v3 point;
+    if (__float_as_int(q0.w) == 1) {
+        const float x = rng_normal(rng);
+        const float y = rng_normal(rng);
+        const float z = rng_normal(rng);
+        point = normalize(mk(x, y, z));
+        point = mk(point.x * par.x, point.y * par.y, point.z * par.z);
+    } else {
+        const float wx = par.y * par.z, wy = par.x * par.z, wz = par.x * par.y;
+        const float u = rng_uniform(rng) * ((wx + wy + wz) - 0.f) + 0.f;  // uniform_real_distribution(a, b): u (b - a) + a
+        const float side = 2.f * ((rng_uniform(rng) < 0.5f ? 1.f : 0.f) - 0.5f);
+        const float c1 = (rng_uniform(rng) * (2.f - 0.f) + 0.f) - 1.f;
+        const float c2 = (rng_uniform(rng) * (2.f - 0.f) + 0.f) - 1.f;
+        if (u < wx) point = mk(side * par.x, c1 * par.y, c2 * par.z);
+        else if (u < wx + wy) point = mk(c1 * par.x, side * par.y, c2 * par.z);
+        else point = mk(c1 * par.x, c2 * par.y, side * par.z);
+    }
+    return quat_rotate(rot, point) + mk(q0.x, q0.y, q0.z);
+}
+// The analytic lights' share of LightSurface::pdf: they follow the triangles in the light list, so their terms
+// are added after the triangles', in list order.
+__device__ __forceinline__ float add_analytic_lights(const DevScene &S, float ps, v3 x, v3 w, int self, uint32_t &tests) {
+    for (uint32_t k = S.ntrilights; k < S.nlights; ++k) {
+        const uint32_t rec = S.lights[k];
+        if ((int)rec == self) continue;
+        ++tests;
+        ps += analytic_light_pdf(S.prims + 3 * (size_t)(rec - S.ntri), x, w);
+    }
+    return ps;
 }
 
 // Triangle::pdf (main.cpp:510-517) of a light triangle the ray x + t w hits
@@ -995,6 +1085,7 @@ __device__ __forceinline__ float light_pdf(const DevScene &S, const LightCache &
     float ps = 0.f;
     if (TREE) {
         ps = light_pdf_tree(S, LC.stack, x, w, self, tests);
+        if (S.nlights > S.ntrilights) ps = add_analytic_lights(S, ps, x, w, self, tests);
         if (ps < kEps || __builtin_isnan(ps) || __builtin_isinf(ps)) return 0.f;
         return ps / (float)S.nlights;
     }
@@ -1023,7 +1114,7 @@ __device__ __forceinline__ float light_pdf(const DevScene &S, const LightCache &
         float t;
         if (tri_test(tp[0], tp[1], tp[2], x, w, t)) ps += light_term(tp[2], tp[3], x, w, t);
     }
-    for (uint32_t k = LC.n; k < S.nlights; ++k) {
+    for (uint32_t k = LC.n; k < S.ntrilights; ++k) {
         const int lt = (int)S.lights[k];
         if (lt == self) continue;
         ++tests;
@@ -1031,6 +1122,7 @@ __device__ __forceinline__ float light_pdf(const DevScene &S, const LightCache &
         float t;
         if (tri_test(tp[0], tp[1], tp[2], x, w, t)) ps += light_term(tp[2], tp[3], x, w, t);
     }
+    if (S.nlights > S.ntrilights) ps = add_analytic_lights(S, ps, x, w, self, tests);
     if (ps < kEps || __builtin_isnan(ps) || __builtin_isinf(ps)) return 0.f;
     return ps / (float)S.nlights;
 }
@@ -1091,20 +1183,25 @@ __device__ __forceinline__ bool sample_vertex(const DevScene &S, const LightCach
             w = mk(0.f, 0.f, 0.f);
         } else {
             const uint32_t k = rng_uint(P.rng, S.nlights);
-            float4 l0, l1, l2;
-            if (k < LC.n) {
-                l0 = LC.recs[4 * k], l1 = LC.recs[4 * k + 1], l2 = LC.recs[4 * k + 2];
+            v3 pt;
+            if (k >= S.ntrilights) {  // an emissive ellipsoid or box
+                pt = analytic_sample_point(S.prims + 3 * (size_t)(S.lights[k] - S.ntri), P.rng);
             } else {
-                const float4 *lp = S.tris + 4 * (size_t)S.lights[k];
-                l0 = lp[0], l1 = lp[1], l2 = lp[2];
+                float4 l0, l1, l2;
+                if (k < LC.n) {
+                    l0 = LC.recs[4 * k], l1 = LC.recs[4 * k + 1], l2 = LC.recs[4 * k + 2];
+                } else {
+                    const float4 *lp = S.tris + 4 * (size_t)S.lights[k];
+                    l0 = lp[0], l1 = lp[1], l2 = lp[2];
+                }
+                float u = rng_uniform(P.rng);  // Triangle::samplePoint, main.cpp:500-508
+                float v = rng_uniform(P.rng);
+                if (u + v > 1.f) {
+                    u = 1.f - u;
+                    v = 1.f - v;
+                }
+                pt = mk(l0.x, l0.y, l0.z) + u * mk(l0.w, l1.x, l1.y) + v * mk(l1.z, l1.w, l2.x);
             }
-            float u = rng_uniform(P.rng);  // Triangle::samplePoint, main.cpp:500-508
-            float v = rng_uniform(P.rng);
-            if (u + v > 1.f) {
-                u = 1.f - u;
-                v = 1.f - v;
-            }
-            const v3 pt = mk(l0.x, l0.y, l0.z) + u * mk(l0.w, l1.x, l1.y) + v * mk(l1.z, l1.w, l2.x);
             w = normalize(pt - pPlus);
         }
         const float dn = dot(w, n);  // Cosine::pdf, main.cpp:748-754

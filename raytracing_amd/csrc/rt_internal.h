@@ -100,7 +100,9 @@ struct FlatScene {
     float grid_origin[3] = {0.f, 0.f, 0.f};
     float grid_cell[3] = {1.f, 1.f, 1.f};
     std::vector<float> tris;        // nslots * 16
-    std::vector<uint32_t> lights;   // leaf-order positions of emissive triangles, loader order
+    std::vector<uint32_t> lights;   // the light list (main.cpp:1096-1098) as record indices: leaf-order positions of the emissive
+                                    // triangles in loader order, then nslots + k for every emissive analytic primitive k
+    uint32_t ntrilights = 0;        // how many of them are triangles
     // tree over the light triangles only (same node format, its own grid) and their records in that
     // tree's leaf order: a triangle record whose word 12 = index in `lights`, word 13 = lights[index]
     std::vector<uint32_t> light_nodes;

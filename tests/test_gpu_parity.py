@@ -1148,6 +1148,66 @@ def test_analytic_primitives(scene_dir, oracle_mod):
         orc.close()
 
 
+@pytest.mark.parametrize("with_tris,light_tree", [(True, False), (False, False), (True, True)])
+def test_emissive_analytic_primitives(scene_dir, oracle_mod, monkeypatch, with_tris, light_tree):
+    """Ellipsoids and boxes that emit (main.cpp:218-239, 320-356, 425-455: samplePoint, pdf, intersectFull,
+    pdfFull; dead code in the reference, whose loader constructs triangles only, so the target is the oracle's
+    restatement, bug for bug: the ellipsoid's second density taken at the first intersection point, a missed
+    second intersection dividing by zero).  They join the light list behind the light triangles.  Inside the
+    Cornell box (whose lamp stays) and alone in the dark: reference-stream render bit for bit in both hit orders
+    with equal segment and light-test counts; both throughput pipelines within 1e-5 with equal segment counts; the
+    analytic lights really light the scene."""
+    import raytracing_amd as rt
+    W, H = 112, 84
+    if light_tree:      # the light triangles' share of the density through the light tree, the primitives' share behind it
+        monkeypatch.setenv("RT_LIGHT_TREE_MIN", "1")
+    base = rt.load_gltf(make_scene(scene_dir, "cornell"), W, H)
+    mats = np.concatenate([base.materials, base.materials[:2]])
+    glow_a, glow_b = len(base.materials), len(base.materials) + 1
+    mats["type"][glow_a:], mats["color"][glow_a:] = 0, 0.8
+    mats["emission"][glow_a], mats["emission"][glow_b] = (9.0, 6.0, 3.0), (2.0, 5.0, 8.0)
+    types = base.materials["type"]
+    emits = np.linalg.norm(base.materials["emission"], axis=1) > 1e-4
+    diffuse, glass, metal = [int(np.flatnonzero((types == t) & ~emits)[0]) for t in (0, 2, 1)]
+    rng = np.random.RandomState(12)
+    prims = _analytic_prims(rt, rng, [diffuse, glass, metal])
+    prims["material"][1], prims["material"][3], prims["material"][5] = glow_a, glow_b, glow_b   # ellipsoid, box, ellipsoid
+    if with_tris:
+        host = rt.HostScene(base.tri_verts, base.tri_material, mats, base.camera, prims=prims)
+    else:
+        host = rt.HostScene(np.zeros((0, 3, 3), np.float32), np.zeros(0, np.uint32), mats, base.camera, prims=prims)
+    gpu = rt.Scene(host, device=0)
+    d = host.as_dict()
+    ntri = host.tri_material.shape[0]
+    assert gpu.stats()["nlights"] == (2 if with_tris else 0) + 3
+    for order, in_tree in ((rt.HITS_REFERENCE_ORDER, True), (rt.HITS_LEAF_ORDER, False)):
+        gpu.set_hit_order(order)
+        orc = oracle_mod.OracleScene(d["tri_verts"], d["tri_material"], d["materials"], d["camera"], d["background"], d["prims"],
+                                     prims_in_tree=in_tree)
+        assert orc.lights().tolist()[-3:] == [ntri + 1, ntri + 3, ntri + 5]
+        ref0, c0 = orc.render(W, H, 4, max_depth=6, rng_mode=0)
+        gpu.reset_counters()
+        _assert_bits_equal_nan(gpu.render(W, H, 4, max_depth=6, rng_mode=0), ref0)
+        c = gpu.counters()
+        assert c["segments"] == c0["segments"]
+        assert c["light_tests"] == c0["light_tests"] or light_tree        # (the tree walk tests fewer light triangles)
+        assert np.nansum(ref0) > 0
+        if not in_tree:
+            ref, c_o = orc.render(W, H, 5, max_depth=6, rng_mode=1, seed=8, spp_begin=2)
+            for pipe in (rt.PIPE_MEGAKERNEL, rt.PIPE_WAVEFRONT):
+                gpu.reset_counters()
+                _assert_close(gpu.render(W, H, 5, max_depth=6, rng_mode=1, seed=8, spp_begin=2, pipeline=pipe), ref, max_nan_pixels=8)
+                assert gpu.counters()["segments"] == c_o["segments"]
+        orc.close()
+    if with_tris:   # against the same scene with the primitives dark
+        dark = mats.copy()
+        dark["emission"][glow_a:] = 0
+        plain, _ = oracle_mod.OracleScene(d["tri_verts"], d["tri_material"], dark, d["camera"], d["background"], d["prims"]).render(
+            W, H, 4, max_depth=6, rng_mode=0)
+        assert np.nanmean(ref0) > 1.2 * np.nanmean(plain)
+    gpu.close()
+
+
 def test_analytic_primitive_ids_with_pad_records(scene_dir, oracle_mod):
     """A scene whose triangle array holds pad records (two-triangle leaves start on even records), plus analytic
     primitives: on the device a primitive's index lies behind the RECORDS, the caller must still see it as

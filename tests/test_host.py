@@ -496,8 +496,9 @@ def test_gltf_glb_ior_background_flags(scene_dir, tmp_path):
 
 def test_analytic_primitive_validation(scene_dir):
     """rt_scene_desc.prims (Plane / Ellipsoid / Box, main.cpp:242-464) is checked on the host before any GPU
-    work: type, unit quaternion, positive radii / extents, a non-zero plane normal, an existing and
-    non-emissive material, at most RT_MAX_PRIMITIVES."""
+    work: type, unit quaternion, positive radii / extents, a non-zero plane normal, an existing material (an
+    emitting one only for ellipsoids and boxes: a plane cannot be sampled, main.cpp:261-267), at most
+    RT_MAX_PRIMITIVES.  An emitting ellipsoid joins the light list behind the light triangles."""
     import raytracing_amd as rt
     base = rt.load_gltf(make_scene(scene_dir, "cornell"), 64, 48)
     emits = np.linalg.norm(base.materials["emission"], axis=1) > 1e-4
@@ -511,8 +512,10 @@ def test_analytic_primitive_validation(scene_dir):
         return rt.build_flat(rt.HostScene(base.tri_verts, base.tri_material, base.materials, base.camera, prims=p))
 
     assert build()["tris"].shape[0] == 36
+    lit = build(material=bright)
+    assert lit["lights"].tolist() == build()["lights"].tolist() + [lit["tris"].shape[0]]
     for bad in (dict(type=3), dict(rotation=[0, 0, 0, 2]), dict(param=[1, 0, 1]), dict(param=[1, -1, 1]),
-                dict(type=rt.PRIM_PLANE, param=[0, 0, 0]), dict(material=99), dict(material=bright),
+                dict(type=rt.PRIM_PLANE, param=[0, 0, 0]), dict(material=99), dict(type=rt.PRIM_PLANE, material=bright),
                 dict(position=[np.nan, 0, 0])):
         with pytest.raises(rt.RtError):
             build(**bad)
