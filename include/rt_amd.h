@@ -196,6 +196,9 @@ typedef struct rt_counters {
      * fraction of those slots that did useful work */
     uint64_t node_lane_slots;
     uint64_t tri_lane_slots;
+    /* wavefront pipeline: rays the trace kernel handed to its second kernel -- their walk of the four-child tree ran
+     * out of stack, or (RT_HITS_REFERENCE_ORDER) they met two primitives at the best distance */
+    uint64_t retraced;
 } rt_counters;
 
 const char *rt_last_error(void);

@@ -43,7 +43,8 @@ class SceneStats(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("segments", C.c_uint64), ("nodes", C.c_uint64), ("tri_tests", C.c_uint64),
-                ("light_tests", C.c_uint64), ("node_lane_slots", C.c_uint64), ("tri_lane_slots", C.c_uint64)]
+                ("light_tests", C.c_uint64), ("node_lane_slots", C.c_uint64), ("tri_lane_slots", C.c_uint64),
+                ("retraced", C.c_uint64)]
 
 
 KERNEL_KINDS = ("extend", "shade", "generate", "accumulate", "mega", "closest_hit", "tonemap", "sort")
@@ -123,6 +124,8 @@ def lib():
                               "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if os.environ.get("RT_AMD_LIB_OLD") and not hasattr(L, name):
+                continue   # timing an older build of the library against this one (tools only)
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args

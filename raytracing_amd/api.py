@@ -219,7 +219,7 @@ class Scene:
         check(_lib.lib().rt_counters_read(self._h, C.byref(c)))
         return dict(segments=int(c.segments), nodes=int(c.nodes), tri_tests=int(c.tri_tests),
                     light_tests=int(c.light_tests), node_lane_slots=int(c.node_lane_slots),
-                    tri_lane_slots=int(c.tri_lane_slots))
+                    tri_lane_slots=int(c.tri_lane_slots), retraced=int(c.retraced))
 
     def set_timing(self, enable):
         """Record HIP events around every kernel of later launches (clears the totals)."""

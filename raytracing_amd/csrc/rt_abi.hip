@@ -40,7 +40,9 @@ constexpr size_t kScratchQcount = kScratchBin + (size_t)kNoAllocPaths * 2;    //
 constexpr size_t kScratchCursors = kScratchQcount + 256;                      // uint32_t[kWfCursorWords]
 constexpr size_t kScratchBinHist = kScratchCursors + rt::kWfCursorWords * sizeof(uint32_t);  // uint32_t[kWfBinWords]
 constexpr size_t kScratchTuner = kScratchBinHist + rt::kWfBinWords * sizeof(uint32_t);             // uint32_t[kWfTuneWords]
-constexpr size_t kScratchBytes = kScratchTuner + rt::kWfTuneWords * sizeof(uint32_t);
+constexpr size_t kScratchRefFrames = kScratchTuner + rt::kWfTuneWords * sizeof(uint32_t);  // RefFrame[kNoAllocRefFrames]
+constexpr size_t kNoAllocRefFrames = (size_t)1 << 20;                                       // 16 MB: (tree depth + 1) x lanes
+constexpr size_t kScratchBytes = kScratchRefFrames + kNoAllocRefFrames * sizeof(rtd::RefFrame);
 }  // namespace
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 
@@ -129,6 +131,7 @@ void free_wavefront(rt_scene *s) {
     dev_free(s, w.cursors, rt::kWfCursorWords);
     dev_free(s, w.tuner, rt::kWfTuneWords);
     dev_free(s, w.binhist, rt::kWfBinWords);
+    dev_free(s, w.ref_frames, (size_t)w.ref_lanes * (w.ref_depth + 1));
     w = rt::WavefrontBuffers();
 }
 
@@ -181,6 +184,11 @@ int ensure_wavefront(rt_scene *s, uint32_t npix, uint32_t slots) {
     RT_WF(hipMemset(w.cursors, 0, rt::kWfCursorWords * sizeof(uint32_t)));
     RT_WF(dev_alloc(s, &w.tuner, rt::kWfTuneWords));
     RT_WF(hipMemset(w.tuner, 0, rt::kWfTuneWords * sizeof(uint32_t)));
+    if (s->flat->ref.available) {  // frames of the reference-order walk of wf_extend_retry_ref
+        w.ref_depth = s->flat->ref.depth;
+        w.ref_lanes = rt::kWfRefLanes;
+        RT_WF(dev_alloc(s, &w.ref_frames, (size_t)w.ref_lanes * (w.ref_depth + 1)));
+    }
 #undef RT_WF
     if (e != hipSuccess) {
         free_wavefront(s);
@@ -621,6 +629,10 @@ int rt_render_noalloc_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t
     wb.sort_min_rays = s->sort_min_rays;
     wb.wide = s->wide_tree;
     wb.ties = s->hit_order != RT_HITS_LEAF_ORDER;
+    wb.ref_depth = s->flat->ref.depth;
+    wb.ref_frames = reinterpret_cast<rtd::RefFrame *>(base + kScratchRefFrames);
+    wb.ref_lanes = (uint32_t)(kNoAllocRefFrames / (wb.ref_depth + 1) / rtd::kBlock) * rtd::kBlock;   // at least 64 blocks: depth <= 64
+    if (wb.ref_lanes > rt::kWfRefLanes) wb.ref_lanes = rt::kWfRefLanes;
     wb.stack_limit = s->stack_limit;
     wb.qcount = reinterpret_cast<uint32_t *>(base + kScratchQcount);
     wb.cursors = reinterpret_cast<uint32_t *>(base + kScratchCursors);
@@ -787,15 +799,16 @@ int rt_counters_read(rt_scene *s, rt_counters *out) {
     std::vector<unsigned long long> raw(kCounterWords);
     RT_HIP(hipDeviceSynchronize());
     RT_HIP(hipMemcpy(raw.data(), s->d_counters, kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    unsigned long long h[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int sh = 0; sh < rtd::kCounterShards; ++sh)
-        for (int k = 0; k < 7; ++k) h[k] += raw[(size_t)sh * rtd::kCounterStride + k];
+        for (int k = 0; k < 8; ++k) h[k] += raw[(size_t)sh * rtd::kCounterStride + k];
     out->segments = h[0] + s->host_segments;
     out->nodes = h[1];
     out->tri_tests = h[2];
     out->light_tests = h[3];
     out->node_lane_slots = h[4];
     out->tri_lane_slots = h[5];
+    out->retraced = h[7];
     if (h[6])
         return fail(RT_ERR_INVALID, "rt_counters_read: " + std::to_string(h[6]) +
                                         " workgroup(s) of a counting launch cut a ray's walk short at the step bound: the "

@@ -230,8 +230,8 @@ __device__ __forceinline__ bool tri_test(float4 q0, float4 q1, float4 q2, v3 o, 
 // height bound (kStack inner levels) is what keeps the stack from overflowing.
 constexpr int kSentinel = 0x7FFFFFFF;  // "stack is empty": never a node index, never a leaf reference
 
-// TIES: the walk only notes (in `tie`) that a second primitive came back at exactly the best distance; the
-// caller then asks ref_closest_hit, which answers in the reference's own order.
+// TIES: the walk only notes (kTieBit of triBest) that a second primitive came back at exactly the best distance;
+// the caller then asks the reference's own walk, which answers in the reference's order.
 template <bool COUNT, int EXIT_LANES = 0, bool HELP = false, bool WIDE = false, bool TIES = false>
 struct Traversal {
     struct f2 {
@@ -253,7 +253,6 @@ struct Traversal {
     // again on the two-child tree
     int limit;
     bool overflow;
-    bool tie;  // TIES: the best distance so far was returned by more than one primitive
 
     // lane_stack: &lds[threadIdx.x]
     __device__ __forceinline__ void bind(int *lane_stack) { stack = lane_stack; }
@@ -292,7 +291,6 @@ struct Traversal {
         leaf = 0;
         sp = 0;
         overflow = false;
-        tie = false;
     }
     __device__ __forceinline__ void idle() {  // a lane with no ray: steps are no-ops
         cur = kSentinel;
@@ -309,16 +307,20 @@ struct Traversal {
     // edge, two coincident faces): the reference keeps whichever its own tree meets first.  Without TIES the one
     // earlier in leaf order wins, whatever tree is walked in whatever order, so that every kernel names the same
     // triangle; with TIES the event is noted and the caller has the ray traced in the reference's order.
+    // (The mark rides in a spare bit of triBest -- record indices stay below 2^26 -- so that a strictly nearer hit
+    // clears it by being assigned, and the hot loop carries no extra register.)
+    static constexpr int kTieBit = 1 << 30;
     __device__ __forceinline__ void consider(float t, int tri) {
         if (t < tBest) {
             tBest = t;
             triBest = tri;
-            if (TIES) tie = false;
         } else if (t == tBest) {
-            if (TIES) tie = true;
+            if (TIES) triBest |= kTieBit;
             else if (tri < triBest) triBest = tri;
         }
     }
+    __device__ __forceinline__ bool tied() const { return TIES && triBest >= 0 && (triBest & kTieBit) != 0; }
+    __device__ __forceinline__ int best() const { return TIES && triBest >= 0 ? (triBest & ~kTieBit) : triBest; }
     __device__ __forceinline__ int pop() {
         if (sp == 0) return kSentinel;
         --sp;
@@ -666,10 +668,17 @@ __device__ __forceinline__ bool analytic_closest(const DevScene &S, v3 o, v3 d, 
 // The recursion is unrolled over a stack of frames, one per call that is waiting for a child: the call's
 // closest hit so far and, while the first child runs, the second child with its box distance.  A frame's
 // `right` is nonzero exactly while the first child is out (children are never the root, node 0).
-// Private memory (1 KB per lane): this is the walk of the validation paths and of the few rays the fast
-// walks hand over, not a throughput path.  The host guarantees depth <= kRefStack.
+// The frames live where the caller says (`frames`, one every `stride` elements): in private memory (1 KB per
+// lane; the validation kernels and the megakernel) or in LDS (wf_extend_retry: a kernel that needs private
+// memory costs every launch a scratch set-up of its own, 0.3 to 1.3 ms here, and that kernel is launched once
+// per bounce).  The host guarantees depth <= kRefStack.
 // ---------------------------------------------------------------------------------------------
 constexpr int kRefStack = 64;
+struct RefFrame {
+    float rd, t;
+    int rec;
+    uint32_t right;
+};
 constexpr float kBigInf = 20000.f;  // BIG_INF, main.cpp:24
 
 // AABB::intersect, main.cpp:180-196, on a node record (sizePlusCenter, negSizePlusCenter, minPoint, maxPoint)
@@ -686,14 +695,32 @@ __device__ __forceinline__ float ref_box_distance(const float4 *n, v3 o, v3 d) {
 
 // tOut / recOut: distance and record index (triangle record, or S.ntri + k) of the reference's answer;
 // recOut < 0 and tOut = INF when it hits nothing.  tOut may be NaN or >= INF for a hit (see above).
-template <bool COUNT>
-__device__ __noinline__ void ref_closest_hit(const DevScene &S, v3 o, v3 d, float &tOut, int &recOut, TraceStats &st) {
-    struct Frame {
-        float rd, t;
-        int rec;
-        uint32_t right;
-    };
-    Frame fr[kRefStack];
+// PRUNE: a child whose TRUE box (minPoint / maxPoint, padded) the ray misses is not entered even where the
+// reference enters it (its slabs are twice the box).  No triangle in there can be hit, so the reference's call
+// returns "nothing" and changes neither its answer nor any later decision; skipping it keeps every answer that
+// is a matter of real hits -- equal distances above all -- and takes the walk from hundreds of node visits,
+// each a dependent trip to memory, to a few dozen (one ray of a 17 930-triangle scene: 1.1 ms -> under 0.1 ms; the
+// kernel that runs this finds a handful of rays per bounce and lasts as long as the slowest of them).  What it gives
+// up are the NaN "hits" of rays lying in a triangle's plane, which are not confined to any box: the validation
+// kernels walk with PRUNE = false.
+__device__ __forceinline__ bool ref_true_box_missed(const float4 *n, v3 o, v3 d) {
+    const float4 q1 = n[1], q2 = n[2];
+    const v3 lo = mk(q1.z, q1.w, q2.x), hi = mk(q2.y, q2.z, q2.w);
+    // padded far beyond the rounding of a hit point (1e-6 of its coordinates and of the distance travelled)
+    const v3 pad = mk(1.0e-3f + 1.0e-4f * __builtin_fmaxf(__builtin_fabsf(lo.x), __builtin_fabsf(hi.x)),
+                      1.0e-3f + 1.0e-4f * __builtin_fmaxf(__builtin_fabsf(lo.y), __builtin_fabsf(hi.y)),
+                      1.0e-3f + 1.0e-4f * __builtin_fmaxf(__builtin_fabsf(lo.z), __builtin_fabsf(hi.z)));
+    const v3 a = vdiv((lo - pad) - o, d), b = vdiv((hi + pad) - o, d);
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a.x, b.x), __builtin_fminf(a.y, b.y)), __builtin_fminf(a.z, b.z));
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a.x, b.x), __builtin_fmaxf(a.y, b.y)), __builtin_fmaxf(a.z, b.z));
+    // fmin / fmax drop a NaN operand (0 / 0: origin on a padded plane of an axis the ray does not move along): that
+    // axis then does not constrain.  Missed only when the comparison says so.
+    return tn > tf * 1.0001f + 1.0e-3f || tf < -1.0e-3f;
+}
+template <bool COUNT, bool PRUNE = false>
+__device__ __forceinline__ void ref_walk(const DevScene &S, v3 o, v3 d, RefFrame *frames, int stride, int depth, float &tOut,
+                                         int &recOut, TraceStats &st) {
+    typedef RefFrame Frame;
     int sp = 0;
     uint32_t cur = 0;
     float rt = kInf;  // what the call that just returned hands back
@@ -734,14 +761,18 @@ __device__ __noinline__ void ref_closest_hit(const DevScene &S, v3 o, v3 d, floa
                 rd = ld - rd;
                 ld -= rd;
             }
-            if (sp < kRefStack) {
+            if (PRUNE) {  // as if the reference had walked the child and found nothing
+                if (ref_true_box_missed(S.rnodes + 4 * (size_t)left, o, d)) ld = kBigInf;
+                if (ref_true_box_missed(S.rnodes + 4 * (size_t)right, o, d)) rd = kBigInf;
+            }
+            if (sp < depth) {
                 if (ld < ct) {  // minDistance = closestIntersection.t, main.cpp:571
-                    fr[sp++] = Frame{rd, ct, crec, right};
+                    frames[sp++ * stride] = Frame{rd, ct, crec, right};
                     cur = left;
                     continue;
                 }
                 if (rd < ct) {
-                    fr[sp++] = Frame{0.f, ct, crec, 0u};
+                    frames[sp++ * stride] = Frame{0.f, ct, crec, 0u};
                     cur = right;
                     continue;
                 }
@@ -751,7 +782,7 @@ __device__ __noinline__ void ref_closest_hit(const DevScene &S, v3 o, v3 d, floa
         rrec = crec;
         bool descend = false;
         while (sp > 0) {  // return into the waiting calls
-            Frame &f = fr[sp - 1];
+            Frame &f = frames[(sp - 1) * stride];
             if (rrec >= 0 && (f.rec < 0 || rt < f.t)) {  // main.cpp:589-593, 598-601
                 f.t = rt;
                 f.rec = rrec;
@@ -773,6 +804,11 @@ __device__ __noinline__ void ref_closest_hit(const DevScene &S, v3 o, v3 d, floa
     }
     tOut = rt;
     recOut = rrec;
+}
+template <bool COUNT, bool PRUNE = false>
+__device__ __noinline__ void ref_closest_hit(const DevScene &S, v3 o, v3 d, float &tOut, int &recOut, TraceStats &st) {
+    RefFrame fr[kRefStack];
+    ref_walk<COUNT, PRUNE>(S, o, d, fr, 1, kRefStack, tOut, recOut, st);
 }
 
 // How a kernel answers where the reference's result depends on its traversal order:
@@ -797,10 +833,10 @@ __device__ __forceinline__ void closest_hit(const DevScene &S, v3 o, v3 d, int *
         if (COUNT && ++rounds > S.step_bound) T.abandon(st);
     }
     tBest = T.tBest;
-    triBest = T.triBest;
-    bool tie = T.tie;
+    triBest = T.best();
+    bool tie = T.tied();
     if (S.nprims) tie = analytic_closest(S, o, d, tBest, triBest) || tie;
-    if (ORDER == kOrderRefTies && tie) ref_closest_hit<COUNT>(S, o, d, tBest, triBest, st);
+    if (ORDER == kOrderRefTies && tie) ref_closest_hit<COUNT, true>(S, o, d, tBest, triBest, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -930,7 +966,7 @@ __device__ __forceinline__ FullHit full_intersect(const float4 *rec, v3 o, v3 d)
     }
     return f;
 }
-__device__ __forceinline__ float analytic_light_pdf(const float4 *rec, v3 o, v3 d) {
+__device__ __noinline__ float analytic_light_pdf(const float4 *rec, v3 o, v3 d) {
     const FullHit i1 = full_intersect(rec, o, d);
     if (!i1.hit) return 0.f;
     const FullHit i2 = i1.inside ? full_intersect(rec, i1.pPlus, -d) : full_intersect(rec, i1.pMinus, d);
@@ -955,7 +991,7 @@ __device__ __forceinline__ float analytic_light_pdf(const float4 *rec, v3 o, v3 
     return fp1 + fp2;
 }
 // Ellipsoid::samplePoint (3 normals) / Box::samplePoint (4 uniforms)
-__device__ __forceinline__ v3 analytic_sample_point(const float4 *rec, uint32_t &rng) {
+__device__ __noinline__ v3 analytic_sample_point(const float4 *rec, uint32_t &rng) {
     const float4 q0 = rec[0], rot = rec[1], q2 = rec[2];
     const v3 par = mk(q2.x, q2.y, q2.z);
     v3 point;
@@ -978,8 +1014,10 @@ __device__ __forceinline__ v3 analytic_sample_point(const float4 *rec, uint32_t 
     return quat_rotate(rot, point) + mk(q0.x, q0.y, q0.z);
 }
 // The analytic lights' share of LightSurface::pdf: they follow the triangles in the light list, so their terms
-// are added after the triangles', in list order.
-__device__ __forceinline__ float add_analytic_lights(const DevScene &S, float ps, v3 x, v3 w, int self, uint32_t &tests) {
+// are added after the triangles', in list order.  (Out of line, like the two functions above: a scene without
+// such lights must not pay for their registers -- inlined into wf_shade they cost it 15 spilled registers and
+// 16 % of its time.  The shading kernels take ALIGHT = false for such scenes and hold no call at all.)
+__device__ __noinline__ float add_analytic_lights(const DevScene &S, float ps, v3 x, v3 w, int self, uint32_t &tests) {
     for (uint32_t k = S.ntrilights; k < S.nlights; ++k) {
         const uint32_t rec = S.lights[k];
         if ((int)rec == self) continue;
@@ -1079,13 +1117,13 @@ __device__ __forceinline__ float light_pdf_tree(const DevScene &S, int *stack, v
     return ps;
 }
 
-template <bool TREE>
+template <bool TREE, bool ALIGHT>
 __device__ __forceinline__ float light_pdf(const DevScene &S, const LightCache &LC, v3 x, v3 w, int self,
                                            uint32_t &tests) {
     float ps = 0.f;
     if (TREE) {
         ps = light_pdf_tree(S, LC.stack, x, w, self, tests);
-        if (S.nlights > S.ntrilights) ps = add_analytic_lights(S, ps, x, w, self, tests);
+        if (ALIGHT && S.nlights > S.ntrilights) ps = add_analytic_lights(S, ps, x, w, self, tests);
         if (ps < kEps || __builtin_isnan(ps) || __builtin_isinf(ps)) return 0.f;
         return ps / (float)S.nlights;
     }
@@ -1122,14 +1160,15 @@ __device__ __forceinline__ float light_pdf(const DevScene &S, const LightCache &
         float t;
         if (tri_test(tp[0], tp[1], tp[2], x, w, t)) ps += light_term(tp[2], tp[3], x, w, t);
     }
-    if (S.nlights > S.ntrilights) ps = add_analytic_lights(S, ps, x, w, self, tests);
+    if (ALIGHT && S.nlights > S.ntrilights) ps = add_analytic_lights(S, ps, x, w, self, tests);
     if (ps < kEps || __builtin_isnan(ps) || __builtin_isinf(ps)) return 0.f;
     return ps / (float)S.nlights;
 }
 
 // Processes the hit (t, tri) of ray (P.o, P.d): fills V, and when it returns true the path
 // continues with the new ray in P.o / P.d at depth P.depth - 1.  Touches P.o, P.d, P.rng, P.depth only.
-template <bool TREE>
+// ALIGHT: the light list may hold emissive analytic primitives (false: it holds triangles only).
+template <bool TREE, bool ALIGHT = true>
 __device__ __forceinline__ bool sample_vertex(const DevScene &S, const LightCache &LC, PathState &P, float t, int tri,
                                               Vertex &V, uint32_t &lightTests) {
     V.op = kOpNone;
@@ -1184,7 +1223,7 @@ __device__ __forceinline__ bool sample_vertex(const DevScene &S, const LightCach
         } else {
             const uint32_t k = rng_uint(P.rng, S.nlights);
             v3 pt;
-            if (k >= S.ntrilights) {  // an emissive ellipsoid or box
+            if (ALIGHT && k >= S.ntrilights) {  // an emissive ellipsoid or box
                 pt = analytic_sample_point(S.prims + 3 * (size_t)(S.lights[k] - S.ntri), P.rng);
             } else {
                 float4 l0, l1, l2;
@@ -1206,7 +1245,7 @@ __device__ __forceinline__ bool sample_vertex(const DevScene &S, const LightCach
         }
         const float dn = dot(w, n);  // Cosine::pdf, main.cpp:748-754
         const float pc = (dn < kEps) ? 0.f : dn * kOneOverPi;
-        const float pdf = 0.5f * pc + 0.5f * light_pdf<TREE>(S, LC, pPlus, w, tri, lightTests);
+        const float pdf = 0.5f * pc + 0.5f * light_pdf<TREE, ALIGHT>(S, LC, pPlus, w, tri, lightTests);
         const float wn = dot(w, n);
         if (wn < 0.f || pdf < kEps) return false;  // V.op stays kOpEmit, main.cpp:1134-1136
         V.op = kOpDiffuse;
@@ -1268,11 +1307,11 @@ __device__ __forceinline__ void fold_forward(const DevScene &S, const LightCache
 }
 
 // Shades the hit (t, tri) of ray (P.o, P.d) in forward form.  Returns true when the path continues.
-template <bool TREE>
+template <bool TREE, bool ALIGHT = true>
 __device__ __forceinline__ bool shade_hit(const DevScene &S, const LightCache &LC, PathState &P, float t, int tri,
                                           uint32_t &lightTests) {
     Vertex V;
-    const bool alive = sample_vertex<TREE>(S, LC, P, t, tri, V, lightTests);
+    const bool alive = sample_vertex<TREE, ALIGHT>(S, LC, P, t, tri, V, lightTests);
     fold_forward(S, LC, P, V);
     return alive;
 }

@@ -375,7 +375,8 @@ __global__ __launch_bounds__(kBlock, WIDE ? kWideWaves : 1) void wf_extend(DevSc
         if (hasRay && T.done()) {
             bool again = WIDE && T.overflow;
             if (!again) {
-                bool tie = TIES && T.tie;
+                bool tie = T.tied();
+                T.triBest = T.best();
                 if (PRIMS) tie = (analytic_closest(S, T.o, T.d, T.tBest, T.triBest) || tie) && TIES;
                 again = tie;
             }
@@ -463,9 +464,8 @@ __global__ __launch_bounds__(kBlock, WIDE ? kWideWaves : 1) void wf_extend(DevSc
     }
 }
 
-// The rays wf_extend gave up on, one lane each: on the two-child tree (whose height bounds the stack), or,
-// REF, by the reference's own walk (scenes whose hits are resolved in the reference's order).
-template <bool COUNT, bool REF>
+// The rays wf_extend gave up on, one lane each, on the two-child tree (whose height bounds the stack).
+template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void wf_extend_retry(DevScene S, WfView V, const uint32_t *__restrict__ retry,
                                                            const uint32_t *__restrict__ retry_count, uint32_t camera_rays) {
     __shared__ int s_stack[kStack * kBlock];
@@ -483,11 +483,51 @@ __global__ __launch_bounds__(kBlock) void wf_extend_retry(DevScene S, WfView V, 
         }
         float t;
         int tri;
-        closest_hit<COUNT, REF ? kOrderRefFull : kOrderLeaf>(S, o, d, s_stack + threadIdx.x, t, tri, st);
+        closest_hit<COUNT>(S, o, d, s_stack + threadIdx.x, t, tri, st);
         V.hit[hitAt] = make_float2(t, __int_as_float(tri));
         ++segs;
     }
-    if (segs) add_counters(S, segs, st, 0u, COUNT);
+    if (segs) {
+        add_counters(S, segs, st, 0u, COUNT);
+        atomicAdd(&S.counters[(size_t)(blockIdx.x & (rtd::kCounterShards - 1)) * rtd::kCounterStride + 7], (unsigned long long)segs);
+    }
+}
+
+// The same list in scenes whose hits are resolved in the reference's order: every ray of it (the rays that met two
+// primitives at the best distance, and those the wide walk ran out of stack on) by the reference's own walk.  The
+// walk's frames lie in global memory, `frames[level * lanes + lane]` (coalesced), lanes = threads of the launch.
+// The kernel is launched once per bounce and finds a handful of rays (on a scene with emissive meshes: the light
+// samples that land exactly on an edge, a few in 10^7); it lasts as long as the slowest of their walks, each node
+// visit two or three dependent trips to memory.  Hence the pruned walk (ref_walk<PRUNE>): 17 930 triangles, 33 M
+// paths per bounce: 1.1 ms per launch unpruned, 0.3 to 0.8 pruned (4.6 % of that frame; 0.4 % of the Cornell frame).
+constexpr uint32_t kRefRetryBlocks = 256;  // x 256 lanes, each with (tree depth + 1) frames of 16 bytes
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void wf_extend_retry_ref(DevScene S, WfView V, const uint32_t *__restrict__ retry,
+                                                               const uint32_t *__restrict__ retry_count, uint32_t camera_rays,
+                                                               RefFrame *__restrict__ frames, int depth) {
+    const uint32_t count = *retry_count;
+    const uint32_t lanes = gridDim.x * kBlock, me = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t segs = 0;
+    TraceStats st{0, 0, 0, 0, 0};
+    for (uint32_t k = me; k < count; k += lanes) {
+        const uint32_t slot = retry[2 * (size_t)k], hitAt = retry[2 * (size_t)k + 1];
+        const float4 r0 = camera_rays ? V.lum[slot] : V.ray[2 * (size_t)slot];
+        v3 o = mk(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]), d = mk(r0.x, r0.y, r0.z);  // see wf_generate
+        if (!camera_rays) {
+            const float4 r1 = V.ray[2 * (size_t)slot + 1];
+            o = mk(r0.x, r0.y, r0.z);
+            d = mk(r0.w, r1.x, r1.y);
+        }
+        float t;
+        int tri;
+        ref_walk<COUNT, true>(S, o, d, frames + me, (int)lanes, depth, t, tri, st);
+        V.hit[hitAt] = make_float2(t, __int_as_float(tri));
+        ++segs;
+    }
+    if (segs) {
+        add_counters(S, segs, st, 0u, COUNT);
+        atomicAdd(&S.counters[(size_t)(blockIdx.x & (rtd::kCounterShards - 1)) * rtd::kCounterStride + 7], (unsigned long long)segs);
+    }
 }
 
 // Shades the hits of the input queue and appends the surviving paths to the output queue.
@@ -517,7 +557,9 @@ constexpr int kShadeWavesCamera = 8;
 // trees of at most 16 levels (the walk pushes at most one reference per level), which lets five instead of four
 // workgroups share a CU (96 VGPRs): -3.7 % on the 15 360-light frame.
 constexpr int kLightStackShort = 16;
-template <bool TREE, bool CAMERA, int LSTACK = kStack>
+// ALIGHT: the light list holds emissive analytic primitives too (their sampling and density code is kept out of
+// the instantiations for scenes without them).
+template <bool TREE, bool CAMERA, int LSTACK = kStack, bool ALIGHT = false>
 __global__ __launch_bounds__(kBlock, TREE ? (LSTACK == kLightStackShort ? 5 : 1) : (CAMERA ? kShadeWavesCamera : kShadeWaves)) void wf_shade(DevScene S, WfView V, const uint32_t *__restrict__ queue_,
                                                     const uint32_t *__restrict__ qcount_in,
                                                     uint32_t *__restrict__ queue_out, uint32_t *__restrict__ qcount_out,
@@ -582,7 +624,7 @@ __global__ __launch_bounds__(kBlock, TREE ? (LSTACK == kLightStackShort ? 5 : 1)
             }
             P.L = mk(0.f, 0.f, 0.f);
             P.depth = depth;  // rayDepth of every hit of this bounce (main.cpp:1188-1199)
-            alive = shade_hit<TREE>(S, LC, P, h.x, __float_as_int(h.y), lightTests);
+            alive = shade_hit<TREE, ALIGHT>(S, LC, P, h.x, __float_as_int(h.y), lightTests);
             if (!queue) {  // first bounce: the camera record makes way for the radiance
                 V.lum[home] = make_float4(P.L.x, P.L.y, P.L.z, 0.f);
             } else if (P.L.x != 0.f || P.L.y != 0.f || P.L.z != 0.f) {  // the path met an emitter (or went NaN): 0 + x == x, so
@@ -780,7 +822,6 @@ inline uint32_t ceil_blocks(uint64_t n) { return (uint32_t)((n + kBlock - 1) / k
 constexpr uint32_t kPersistentBlocks = 256u * 8u;  // 256 CUs x 8 workgroups for grid-stride kernels
 constexpr uint32_t kExtendBlocks = 256u * 6u;      // 256 CUs x 6 resident workgroups (24 KB of LDS each); the wide walk: kWideWaves
 constexpr uint32_t kRetryGrid = 64;                // the retry list is empty or nearly so
-constexpr uint32_t kRetryGridTies = 1024;          // ... unless faces of the scene coincide (a box standing on a floor: a percent of the rays)
 
 }  // namespace
 
@@ -892,18 +933,24 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
 #undef RT_EXT
             hipLaunchKernelGGL(ext, dim3(egrid), dim3(kBlock), 0, stream, S, V, qshade, qsorted, traced, wb.qcount + in,
                                wb.qcount + out, wb.cursors, retry, retryCount, wb.stack_limit, tune, b, wb.sort_min_rays);
-            if (wb.wide || wb.ties) {
-                auto again = wb.ties ? (count ? wf_extend_retry<true, true> : wf_extend_retry<false, true>)
-                                     : (count ? wf_extend_retry<true, false> : wf_extend_retry<false, false>);
-                hipLaunchKernelGGL(again, dim3(wb.ties ? kRetryGridTies : kRetryGrid), dim3(kBlock), 0, stream, S, V, retry, retryCount,
-                                   b == 0 ? 1u : 0u);
+            if (wb.ties) {
+                const int depth = (int)wb.ref_depth + 1;
+                const uint32_t rblocks = wb.ref_lanes / kBlock;   // the host sized the frame buffer for this many lanes
+                hipLaunchKernelGGL(count ? wf_extend_retry_ref<true> : wf_extend_retry_ref<false>, dim3(rblocks), dim3(kBlock), 0, stream,
+                                   S, V, retry, retryCount, b == 0 ? 1u : 0u, wb.ref_frames, depth);
+            } else if (wb.wide) {
+                hipLaunchKernelGGL(count ? wf_extend_retry<true> : wf_extend_retry<false>, dim3(kRetryGrid), dim3(kBlock), 0, stream, S, V,
+                                   retry, retryCount, b == 0 ? 1u : 0u);
             }
             timer.end(stream);
             timer.begin(kKernShade, stream);
-            auto shade = !S.light_tree ? (qshade ? wf_shade<false, false> : wf_shade<false, true>)
-                         : S.light_tree <= (uint32_t)kLightStackShort
-                             ? (qshade ? wf_shade<true, false, kLightStackShort> : wf_shade<true, true, kLightStackShort>)
-                             : (qshade ? wf_shade<true, false> : wf_shade<true, true>);
+#define RT_SHADE(A_)                                                                                                  \
+    (!S.light_tree ? (qshade ? wf_shade<false, false, kStack, A_> : wf_shade<false, true, kStack, A_>)                    \
+     : S.light_tree <= (uint32_t)kLightStackShort                                                                         \
+         ? (qshade ? wf_shade<true, false, kLightStackShort, A_> : wf_shade<true, true, kLightStackShort, A_>)            \
+         : (qshade ? wf_shade<true, false, kStack, A_> : wf_shade<true, true, kStack, A_>))
+            auto shade = S.nlights > S.ntrilights ? RT_SHADE(true) : RT_SHADE(false);
+#undef RT_SHADE
             // as many workgroups as stay resident (2048 at six per CU ran the last quarter of them after the rest:
             // 25.4 instead of 24.7 ms per pass); the light-tree variant balances better with more, smaller shares
             const uint32_t sblocks = 256u * (!S.light_tree && qshade ? (uint32_t)kShadeWaves : 8u);

@@ -88,6 +88,7 @@ constexpr size_t kWfCountWords = 64;  // queue lengths [0], [1], retry count [2]
 constexpr size_t kWfTuneWords = 128;  // the sort tuner's books (rt_kernels.hip: SortChoice)
 constexpr size_t kWfCursorWords = 8 * 1024;  // 8 cursors, 4 KB apart (rt_kernels.hip: kShards x kCursorStride)
 constexpr size_t kWfBinWords = 2 * 4096;     // histogram + cursors of the ray-sorting cells (rt_device.h: kBins)
+constexpr uint32_t kWfRefLanes = 256 * 256;  // lanes of the reference-order retry kernel (scene-owned scratch)
 constexpr size_t kWfBytesPerPath = 16 + 16 + 16 + 16 + 8 + 4 + 4 + 8 + 2;
 struct WavefrontBuffers {
     uint32_t capacity = 0;
@@ -105,6 +106,9 @@ struct WavefrontBuffers {
     uint32_t *tuner = nullptr;  // kWfTuneWords words, zero when allocated and then the tuner's own (mode 2)
     bool wide = true;         // wf_extend walks the four-child tree
     bool ties = false;        // rays that met two primitives at the best distance are traced again in the reference's order
+    uint32_t ref_depth = 0;   // ... by a walk over the reference's own tree: its deepest level,
+    rtd::RefFrame *ref_frames = nullptr;  // (ref_depth + 1) x ref_lanes frames of that walk,
+    uint32_t ref_lanes = 0;   // and the lanes (a multiple of 256) the frames are laid out for
     int stack_limit = 24;     // entries of the traversal stack the wide walk may use (the kernel caps it at its own 20; less only in tests)
     uint32_t *qcount = nullptr; // kWfCountWords words: queue lengths, retry count (device)
     uint32_t *cursors = nullptr; // work cursors of the extend kernel, kWfCursorWords words
