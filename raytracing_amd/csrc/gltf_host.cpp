@@ -112,6 +112,46 @@ std::vector<char> decode_base64(const std::string &text, size_t begin, size_t nb
     return outv;
 }
 
+using jsonmin::Value;
+
+// A node's own matrix by the reference's loading rules (main.cpp:958-1003).  The three factors are written as
+// row-major arrays, multiplied as scale x rotation^T x translation and transposed at the end; a `matrix` property
+// then overwrites the result element by element.  The float operations, zeros and ones included, are kept in
+// exactly this sequence: the transformed vertices have to come out bit-identical to the reference's.
+hm::mat4 local_matrix_of(const Value &node) {
+    auto triple = [&node](const char *key, float fallback) {
+        if (!node.contains(key)) return hm::V3(fallback, fallback, fallback);
+        const Value &v = node.at(key);
+        return hm::V3(v.idx(0).as_float(), v.idx(1).as_float(), v.idx(2).as_float());
+    };
+    const hm::vec3 t = triple("translation", 0.f), s = triple("scale", 1.f);
+    hm::quat q{1.f, 0.f, 0.f, 0.f};
+    if (node.contains("rotation")) {  // glTF order: x, y, z, w
+        const Value &r = node.at("rotation");
+        q = hm::quat{r.idx(3).as_float(), r.idx(0).as_float(), r.idx(1).as_float(), r.idx(2).as_float()};
+    }
+    const float tRows[16] = {1.f, 0.f, 0.f, t.x, 0.f, 1.f, 0.f, t.y, 0.f, 0.f, 1.f, t.z, 0.f, 0.f, 0.f, 1.f};
+    const float sRows[16] = {s.x, 0.f, 0.f, 0.f, 0.f, s.y, 0.f, 0.f, 0.f, 0.f, s.z, 0.f, 0.f, 0.f, 0.f, 1.f};
+    hm::mat4 m = hm::transpose(hm::mat4_from16(sRows) * hm::transpose(hm::to_mat4(q)) * hm::mat4_from16(tRows));
+    if (node.contains("matrix")) {
+        const Value &mv = node.at("matrix");
+        for (int i = 0; i < 16; ++i) hm::elem(m.c[i / 4], i % 4) = mv.idx((size_t)i).as_float();
+    }
+    return m;
+}
+
+std::vector<size_t> child_indices_of(const Value &node, size_t nnodes) {
+    std::vector<size_t> out;
+    if (!node.contains("children")) return out;
+    for (const Value &c : node.at("children").a) {
+        const size_t k = (size_t)c.as_index();
+        if (k >= nnodes) throw std::runtime_error("node child index out of range");
+        out.push_back(k);
+    }
+    return out;
+}
+
+
 void load(const std::string &path, uint32_t width, uint32_t height, uint32_t flags, rt_host_scene &out) {
     using jsonmin::Value;
     std::ifstream in(path, std::ios::binary);
@@ -268,90 +308,52 @@ void load(const std::string &path, uint32_t width, uint32_t height, uint32_t fla
     size_t cameraNode = (size_t)-1;
 
     const std::vector<Value> &nodes = data.at("nodes").a;
-    std::vector<hm::mat4> transitions;
-    std::vector<std::vector<size_t>> children;
-    for (const Value &node : nodes) {  // main.cpp:958-1020
-        hm::vec3 translation = hm::V3(0.f, 0.f, 0.f);
-        if (node.contains("translation")) {
-            const Value &t = node.at("translation");
-            translation = hm::V3(t.idx(0).as_float(), t.idx(1).as_float(), t.idx(2).as_float());
-        }
-        const float tvals[16] = {1.f, 0.f, 0.f, translation.x, 0.f, 1.f, 0.f, translation.y,
-                                 0.f, 0.f, 1.f, translation.z, 0.f, 0.f, 0.f, 1.f};
-        hm::mat4 translationMatrix = hm::mat4_from16(tvals);
-
-        hm::quat rotation{1.f, 0.f, 0.f, 0.f};
-        if (node.contains("rotation")) {
-            const Value &r = node.at("rotation");
-            rotation.x = r.idx(0).as_float();
-            rotation.y = r.idx(1).as_float();
-            rotation.z = r.idx(2).as_float();
-            rotation.w = r.idx(3).as_float();
-        }
-        hm::mat4 rotationMatrix = hm::transpose(hm::to_mat4(rotation));
-
-        hm::vec3 scale = hm::V3(1.f, 1.f, 1.f);
-        if (node.contains("scale")) {
-            const Value &s = node.at("scale");
-            scale = hm::V3(s.idx(0).as_float(), s.idx(1).as_float(), s.idx(2).as_float());
-        }
-        const float svals[16] = {scale.x, 0.f, 0.f, 0.f, 0.f, scale.y, 0.f, 0.f,
-                                 0.f, 0.f, scale.z, 0.f, 0.f, 0.f, 0.f, 1.f};
-        hm::mat4 scaleMat = hm::mat4_from16(svals);
-
-        hm::mat4 transition = hm::transpose(scaleMat * rotationMatrix * translationMatrix);
-        if (node.contains("matrix")) {
-            const Value &mv = node.at("matrix");
-            for (int i = 0; i < 16; ++i) hm::elem(transition.c[i / 4], i % 4) = mv.idx((size_t)i).as_float();
-        }
-        translation = hm::V3(transition.c[3].x, transition.c[3].y, transition.c[3].z);
-        rotation = hm::to_quat(transition);
-        transitions.push_back(transition);
-
-        std::vector<size_t> ch;
-        if (node.contains("children"))
-            for (const Value &c : node.at("children").a) {
-                size_t k = (size_t)c.as_index();
-                if (k >= nodes.size()) throw std::runtime_error("node child index out of range");
-                ch.push_back(k);
-            }
-        children.push_back(ch);
-
-        if (node.contains("camera")) {  // main.cpp:1012-1019
-            float yfov = data.at("cameras").idx((size_t)node.at("camera").as_index()).at("perspective")
-                             .at("yfov").as_float();
+    std::vector<hm::mat4> world;               // per node: local matrix here, composed with its ancestors' below
+    std::vector<std::vector<size_t>> kids;
+    world.reserve(nodes.size());
+    kids.reserve(nodes.size());
+    for (const Value &node : nodes) {
+        world.push_back(local_matrix_of(node));
+        kids.push_back(child_indices_of(node, nodes.size()));
+        if (node.contains("camera")) {
+            // main.cpp:1012-1019: position and orientation from this node's OWN matrix; every camera node turns
+            // the axes once more (they are not reset between nodes)
+            const Value &cams = data.at("cameras");
+            const float yfov = cams.idx((size_t)node.at("camera").as_index()).at("perspective").at("yfov").as_float();
             tanY = std::tan(yfov / 2.f);
-            cameraNode = transitions.size() - 1;
-            camPos = translation;
-            camRight = hm::rotate(rotation, camRight);
-            camUp = hm::rotate(rotation, camUp);
-            camFwd = hm::rotate(rotation, camFwd);
+            cameraNode = world.size() - 1;
+            const hm::mat4 &m = world.back();
+            const hm::quat q = hm::to_quat(m);
+            camPos = hm::V3(m.c[3].x, m.c[3].y, m.c[3].z);
+            camRight = hm::rotate(q, camRight);
+            camUp = hm::rotate(q, camUp);
+            camFwd = hm::rotate(q, camFwd);
         }
     }
 
     if (flags & RT_GLTF_HIERARCHY) {
         // world = parent's world * local, parents first whatever their indices
-        std::vector<size_t> parent(transitions.size(), (size_t)-1);
-        for (size_t i = 0; i < transitions.size(); ++i)
-            for (size_t child : children[i]) {
+        std::vector<size_t> parent(world.size(), (size_t)-1);
+        for (size_t i = 0; i < world.size(); ++i)
+            for (size_t child : kids[i]) {
                 if (parent[child] != (size_t)-1) throw std::runtime_error("node has two parents");
                 parent[child] = i;
             }
         std::vector<size_t> order;
         std::vector<size_t> stack;
-        for (size_t i = 0; i < transitions.size(); ++i)
+        for (size_t i = 0; i < world.size(); ++i)
             if (parent[i] == (size_t)-1) stack.push_back(i);
         while (!stack.empty()) {
             const size_t i = stack.back();
             stack.pop_back();
             order.push_back(i);
-            for (size_t child : children[i]) stack.push_back(child);
+            for (size_t child : kids[i]) stack.push_back(child);
         }
-        if (order.size() != transitions.size()) throw std::runtime_error("node hierarchy has a cycle");
+        if (order.size() != world.size()) throw std::runtime_error("node hierarchy has a cycle");
         for (size_t i : order)
-            if (parent[i] != (size_t)-1) transitions[i] = transitions[parent[i]] * transitions[i];
+            if (parent[i] != (size_t)-1) world[i] = world[parent[i]] * world[i];
         if (cameraNode != (size_t)-1) {
-            const hm::mat4 &w = transitions[cameraNode];
+            const hm::mat4 &w = world[cameraNode];
             const hm::quat q = hm::to_quat(w);
             camPos = hm::V3(w.c[3].x, w.c[3].y, w.c[3].z);
             camRight = hm::rotate(q, hm::V3(1.f, 0.f, 0.f));
@@ -359,13 +361,13 @@ void load(const std::string &path, uint32_t width, uint32_t height, uint32_t fla
             camFwd = hm::rotate(q, hm::V3(0.f, 0.f, -1.f));
         }
     } else {
-        for (size_t i = 0; i < transitions.size(); ++i)  // main.cpp:1022-1026
-            for (size_t child : children[i]) transitions[child] = transitions[i] * transitions[child];
+        for (size_t i = 0; i < world.size(); ++i)  // main.cpp:1022-1026
+            for (size_t child : kids[i]) world[child] = world[i] * world[child];
     }
 
     out.tri_verts.clear();
     out.tri_material.clear();
-    for (size_t i = 0; i < transitions.size(); ++i) {  // main.cpp:1028-1101
+    for (size_t i = 0; i < world.size(); ++i) {  // main.cpp:1028-1101
         if (!nodes[i].contains("mesh")) continue;
         size_t meshIdx = (size_t)nodes[i].at("mesh").as_index();
         if (meshIdx >= meshes.size()) throw std::runtime_error("node names a missing mesh");
@@ -395,7 +397,7 @@ void load(const std::string &path, uint32_t width, uint32_t height, uint32_t fla
             else throw std::runtime_error("Unsupported accessor component type, expected 5123 or 5125");
 
             const size_t indexBase = vi.byteOffset + ((flags & RT_GLTF_INDEX_OFFSET) ? ai.byteOffset : 0);
-            const hm::mat4 &m = transitions[i];
+            const hm::mat4 &m = world[i];
             for (size_t j = 0; j + 2 < ai.count; j += 3) {
                 size_t idx[3];
                 for (size_t k = 0; k < 3; ++k) {

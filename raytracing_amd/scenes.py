@@ -269,13 +269,13 @@ def heightfield_scene(path, nx=224, nz=224):
 
 
 def sphere_field_scene(path, n_spheres=780, subdiv=3, ground=64, seed=1234, glass_fraction=1.0 / 3.0,
-                       metal_fraction=1.0 / 3.0):
+                       metal_fraction=1.0 / 3.0, ground_kind=DIFFUSER):
     """A terrain, `n_spheres` instanced icospheres (20*4^subdiv triangles each) with diffuse /
     metallic / dielectric materials in the given proportions and four emissive quads.
     Defaults: 780 * 1280 + 2*64*64 + 8 = 1 006 600 triangles."""
     rng = np.random.RandomState(seed)
     g = GltfBuilder()
-    m_ground = g.material(DIFFUSER, (0.55, 0.55, 0.5))
+    m_ground = g.material(ground_kind, (0.55, 0.55, 0.5))
     m_light = g.material(DIFFUSER, (0.8, 0.8, 0.8), emission=(1.0, 0.9, 0.8), strength=25.0)
     diffuse = [g.material(DIFFUSER, c) for c in ((0.7, 0.2, 0.2), (0.2, 0.6, 0.25), (0.25, 0.3, 0.75), (0.7, 0.65, 0.3))]
     metals = [g.material(METALLIC, c) for c in ((0.95, 0.95, 0.95), (0.95, 0.8, 0.45), (0.75, 0.8, 0.95))]

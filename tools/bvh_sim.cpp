@@ -74,6 +74,7 @@ static std::vector<WNode> g_wide;
 static std::vector<int> g_h2;  // two-child height (inner levels) of every two-child node
 
 static int h2_of(int32_t ref) { return ref < 0 ? 0 : g_h2[ref]; }
+static int32_t maybe_merge(int32_t ref);
 static int calc_h2(uint32_t node) {
     int h = 1 + std::max(child_ref(node, 0) >= 0 ? calc_h2((uint32_t)child_ref(node, 0)) : 0,
                          child_ref(node, 1) >= 0 ? calc_h2((uint32_t)child_ref(node, 1)) : 0);
@@ -116,7 +117,7 @@ static int32_t collapse(uint32_t node2, int budget, int used) {
     w.n = 2;
     for (int c = 0; c < 2; ++c) {
         w.box[c] = child_box(node2, c);
-        w.ref[c] = child_ref(node2, c);
+        w.ref[c] = maybe_merge(child_ref(node2, c));
     }
     for (;;) {
         if (w.n >= g_maxArity) break;
@@ -137,9 +138,9 @@ static int32_t collapse(uint32_t node2, int budget, int used) {
         if (best < 0) break;
         uint32_t y = (uint32_t)w.ref[best];
         w.box[best] = child_box(y, 0);
-        w.ref[best] = child_ref(y, 0);
+        w.ref[best] = maybe_merge(child_ref(y, 0));
         w.box[w.n] = child_box(y, 1);
-        w.ref[w.n] = child_ref(y, 1);
+        w.ref[w.n] = maybe_merge(child_ref(y, 1));
         ++w.n;
     }
     g_stackNeedMax = std::max<long>(g_stackNeedMax, used + w.n - 1);
@@ -154,9 +155,43 @@ static int32_t collapse(uint32_t node2, int budget, int used) {
     return id;
 }
 
-struct Counts { double nodes = 0, tris = 0, boxes = 0; long maxsp = 0; };
+struct Counts { double nodes = 0, tris = 0, boxes = 0, leaves = 0; long maxsp = 0; };
+
+// Leaves merged for the "up to g_leafMax triangles per leaf" model: a two-child subtree that holds no more
+// than that becomes one leaf (one fetch of a line of packed geometry records); its reference is kMergedBase - index.
+static int g_leafMax = 0;
+static const int32_t kMergedBase = -(1 << 30);
+static std::vector<std::vector<int32_t>> g_merged;
+static std::vector<int> g_ntri2;  // triangles below every two-child node
+static int ntri_of(int32_t ref) { return ref < 0 ? (int)((~(uint32_t)ref & 7u) + 1u) : g_ntri2[ref]; }
+static int calc_ntri(uint32_t node) {
+    int n = 0;
+    for (int c = 0; c < 2; ++c) {
+        const int32_t r = child_ref(node, c);
+        n += r >= 0 ? calc_ntri((uint32_t)r) : ntri_of(r);
+    }
+    g_ntri2[node] = n;
+    return n;
+}
+static void gather_leaves(int32_t ref, std::vector<int32_t> &out) {
+    if (ref < 0) { out.push_back(ref); return; }
+    gather_leaves(child_ref((uint32_t)ref, 0), out);
+    gather_leaves(child_ref((uint32_t)ref, 1), out);
+}
+static int32_t maybe_merge(int32_t ref) {
+    if (ref < 0 || !g_leafMax || g_ntri2[ref] > g_leafMax) return ref;
+    g_merged.emplace_back();
+    gather_leaves(ref, g_merged.back());
+    return kMergedBase - (int32_t)(g_merged.size() - 1);
+}
 
 static void leaf_tests(int32_t ref, const Ray &r, float &tBest, int &best, Counts &c) {
+    if (ref <= kMergedBase) {
+        c.leaves -= (double)g_merged[(size_t)(kMergedBase - ref)].size() - 1.0;  // one line, not one per part
+        for (int32_t part : g_merged[(size_t)(kMergedBase - ref)]) leaf_tests(part, r, tBest, best, c);
+        return;
+    }
+    c.leaves += 1;
     uint32_t u = ~(uint32_t)ref, first = u >> 3, n = (u & 7u) + 1u;
     for (uint32_t k = 0; k < n; ++k) {
         float t;
@@ -261,6 +296,8 @@ int main(int argc, char **argv) {
     printf("nodes %u tris %u height %u\n", info[0], info[1], info[3]);
     g_h2.assign(info[0], 0);
     calc_h2(0);
+    g_ntri2.assign(info[0], 0);
+    calc_ntri(0);
 
     // rays: camera rays, then three bounces off the hits in cosine-distributed directions
     std::mt19937 rng(7);
@@ -322,7 +359,7 @@ int main(int argc, char **argv) {
                 (void)mism;
             }
             double n = (double)gen[b].size();
-            printf(" | b%d: %5.1f nodes %5.1f boxes %4.1f tris sp %ld", b, c.nodes / n, c.boxes / n, c.tris / n, c.maxsp);
+            printf(" | b%d: %5.1f nodes %5.1f boxes %4.1f tris %4.2f leaves sp %ld", b, c.nodes / n, c.boxes / n, c.tris / n, c.leaves / n, c.maxsp);
             if (key) {
                 char buf[160];
                 snprintf(buf, sizeof buf, "%s{\"bounce\": %d, \"rays\": %zu, \"nodes_per_ray\": %.3f, \"tri_tests_per_ray\": %.3f}", b ? ", " : "", b,
@@ -334,10 +371,12 @@ int main(int argc, char **argv) {
         printf("\n");
     };
     report("two-child tree", false, "two_child_tree");
-    struct Cfg { const char *name; int mode, low, budget, arity, order, qbits; };
+    struct Cfg { const char *name; int mode, low, budget, arity, order, qbits, leafMax; };
     const Cfg cfgs[] = {
         {"4-wide, no stack bound", 0, 0, 1000, 4},
         {"4-wide, 8-bit boxes in a node frame", 0, 0, 1000, 4, 0, 8},
+        {"4-wide, 8-bit boxes, leaves of up to 3", 0, 0, 1000, 4, 0, 8, 3},
+        {"4-wide, 8-bit boxes, leaves of up to 4", 0, 0, 1000, 4, 0, 8, 4},
         {"4-wide, 7-bit boxes in a node frame", 0, 0, 1000, 4, 0, 7},
         {"4-wide, 6-bit boxes in a node frame", 0, 0, 1000, 4, 0, 6},
         {"4-wide, 5-bit boxes in a node frame", 0, 0, 1000, 4, 0, 5},
@@ -354,13 +393,15 @@ int main(int argc, char **argv) {
     for (const Cfg &cf : cfgs) {
         g_wide.clear();
         g_mode = cf.mode, g_low = cf.low, g_maxArity = cf.arity, g_order = cf.order, g_qbits = cf.qbits;
+        g_leafMax = cf.leafMax;
+        g_merged.clear();
         g_stackNeedMax = 0;
         collapse(0, cf.budget, 0);
         double fill = 0;
         for (const WNode &w : g_wide) fill += w.n;
         char nm[128];
         snprintf(nm, sizeof nm, "%s (%zu nodes, fill %.2f, need %ld)", cf.name, g_wide.size(), fill / g_wide.size(), g_stackNeedMax);
-        report(nm, true, cf.qbits == 8 ? "four_child_tree_8bit_boxes" : nullptr);
+        report(nm, true, cf.qbits == 8 && !cf.leafMax ? "four_child_tree_8bit_boxes" : nullptr);
     }
     if (argc > 3) {
         FILE *f = fopen(argv[3], "w");
