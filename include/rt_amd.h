@@ -327,8 +327,9 @@ int rt_scene_reserve(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_
  * capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.
  * Same estimator, kernels and results as rt_render_dev(..., RT_RNG_COUNTER, seed, RT_PIPE_WAVEFRONT, ...)
  * (bit-identical sums), but the path records, queues and cursors live in a fixed array inside the
- * library's code object (189 MB per GPU, held from the library's first launch on that GPU until the
- * process ends) instead of scene-owned allocations, and the call makes no hipMalloc / hipFree.
+ * library's code object (206 MB per GPU: 189 MB of path state for 2^21 paths and 17 MB of frames for the
+ * reference-order walker; held from the library's first launch on that GPU until the process ends)
+ * instead of scene-owned allocations, and the call makes no hipMalloc / hipFree.
  * Limit: width * height <= RT_NOALLOC_MAX_PIXELS (one 1920x1080 frame fits), RT_ERR_LIMIT beyond;
  * smaller images keep up to 64 frames of samples in flight.  Every call on a GPU shares that GPU's
  * array, whatever the scene: calls that overlap on one GPU (two streams, two threads) race.  The ray-sorting

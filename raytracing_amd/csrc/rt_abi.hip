@@ -24,7 +24,7 @@ void set_error(const std::string &msg) { g_error = msg; }
 // Path records, index queues, queue counters and work cursors of the wavefront pipeline for
 // kNoAllocPaths paths in flight, laid out back to back in one array that is part of the library's code
 // object: every GPU the library runs on holds its own copy from the first launch on that GPU until the
-// process ends (189 MB).  Host code must not use the array's name as an address: the address on a
+// process ends (206 MB: 90 bytes per path, and 2^20 frames of the reference-order walker).  Host code must not use the array's name as an address: the address on a
 // given GPU comes from hipGetSymbolAddress with that GPU current (scratch_of below).
 namespace {
 constexpr uint32_t kNoAllocPaths = RT_NOALLOC_MAX_PIXELS;  // one path per pixel at least
