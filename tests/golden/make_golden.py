@@ -11,6 +11,10 @@ absent), so nothing here was produced BY the reference:
   cornell_64x48.npz  oracle outputs for the generated Cornell scene: primary-hit ids / distances and
                      4-spp radiance sums in both RNG modes.  They pin the ORACLE against regressions
                      and give the GPU tests a committed target; they do not pin it to the reference.
+  cornell_onfloor_64x48.npz
+                     the same for the Cornell box whose boxes stand ON the floor: coincident faces, so ids and
+                     sums depend on the order in which the reference's own tree is walked (1381 of the render's
+                     22 k rays meet two faces at exactly the same distance).
   emissive_48x36.npz the same for the emissive-mesh scene at 160 light triangles (light-pdf sums over many
                      lights; the GPU evaluates them through its light tree).
 """
@@ -65,6 +69,16 @@ def main():
                         sum_counter_rng=ctr, segments=np.array([cnt0["segments"], cnt1["segments"]], dtype=np.uint64),
                         tri_verts=sc["tri_verts"])
 
+    with tempfile.TemporaryDirectory() as d:
+        sc = gltf_ref.parse_gltf(scenes.cornell_box(os.path.join(d, "cornell_onfloor.gltf"), on_floor=True), W, H)
+    orc = oracle.OracleScene(sc["tri_verts"], sc["tri_material"], sc["materials"], sc["camera"])
+    ids, t, tie, _ = orc.trace_primary(W, H)
+    ref, cnt0 = orc.render(W, H, spp, max_depth=8, rng_mode=0)
+    ctr, cnt1 = orc.render(W, H, spp, max_depth=8, rng_mode=1, seed=0x5EED, spp_begin=2)
+    np.savez_compressed(os.path.join(HERE, "cornell_onfloor_64x48.npz"), ids=ids, t=t, tie=tie, sum_reference_rng=ref,
+                        sum_counter_rng=ctr, segments=np.array([cnt0["segments"], cnt1["segments"]], dtype=np.uint64),
+                        tri_verts=sc["tri_verts"])
+
     W, H, spp = 48, 36, 2
     with tempfile.TemporaryDirectory() as d:
         sc = gltf_ref.parse_gltf(scenes.emissive_mesh_scene(os.path.join(d, "emissive.gltf"), subdiv=1, lamps=2), W, H)
@@ -76,7 +90,7 @@ def main():
                         sum_counter_rng=ctr, segments=np.array([cnt0["segments"], cnt1["segments"]], dtype=np.uint64),
                         light_tests=np.array([cnt0["light_tests"], cnt1["light_tests"]], dtype=np.uint64),
                         tri_verts=sc["tri_verts"])
-    print("wrote rng_kat.json, cornell_64x48.npz and emissive_48x36.npz")
+    print("wrote rng_kat.json, cornell_64x48.npz, cornell_onfloor_64x48.npz and emissive_48x36.npz")
 
 
 if __name__ == "__main__":

@@ -55,6 +55,21 @@ def test_golden_cornell(oracle_mod, scene_dir):
     assert [c0["segments"], c1["segments"]] == [int(x) for x in g["segments"]]
 
 
+def test_golden_cornell_onfloor(oracle_mod, scene_dir):
+    """Coincident faces (the boxes stand on the floor): the fixture pins the order in which the oracle's restatement
+    of BVH::build / BVH::intersect resolves equal distances."""
+    g = np.load(os.path.join(GOLDEN, "cornell_onfloor_64x48.npz"))
+    sc, orc = _oracle_scene(oracle_mod, make_scene(scene_dir, "cornell_onfloor"), 64, 48)
+    assert np.array_equal(sc["tri_verts"], g["tri_verts"])
+    ids, t, tie, _ = orc.trace_primary(64, 48)
+    assert np.array_equal(ids, g["ids"]) and np.array_equal(t.view(np.uint32), g["t"].view(np.uint32))
+    ref, c0 = orc.render(64, 48, 4, max_depth=8, rng_mode=0)
+    ctr, c1 = orc.render(64, 48, 4, max_depth=8, rng_mode=1, seed=0x5EED, spp_begin=2)
+    assert np.array_equal(ref.view(np.uint32), g["sum_reference_rng"].view(np.uint32))
+    assert np.array_equal(ctr.view(np.uint32), g["sum_counter_rng"].view(np.uint32))
+    assert [c0["segments"], c1["segments"]] == [int(x) for x in g["segments"]]
+
+
 def test_golden_emissive(oracle_mod, scene_dir):
     g = np.load(os.path.join(GOLDEN, "emissive_48x36.npz"))
     sc, orc = _oracle_scene(oracle_mod, make_scene(scene_dir, "emissive", subdiv=1, lamps=2), 48, 36)
