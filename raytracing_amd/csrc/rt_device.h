@@ -669,9 +669,9 @@ __device__ __forceinline__ bool analytic_closest(const DevScene &S, v3 o, v3 d, 
 // closest hit so far and, while the first child runs, the second child with its box distance.  A frame's
 // `right` is nonzero exactly while the first child is out (children are never the root, node 0).
 // The frames live where the caller says (`frames`, one every `stride` elements): in private memory (1 KB per
-// lane; the validation kernels and the megakernel) or in LDS (wf_extend_retry: a kernel that needs private
-// memory costs every launch a scratch set-up of its own, 0.3 to 1.3 ms here, and that kernel is launched once
-// per bounce).  The host guarantees depth <= kRefStack.
+// lane; the validation kernels and the megakernel) or in a global buffer the host sized for the tree's depth
+// (wf_extend_retry_ref: lane-interleaved, so that neighbouring lanes' frames of one level share lines).  At most
+// `depth` frames are used; the host guarantees tree depth <= depth <= kRefStack.
 // ---------------------------------------------------------------------------------------------
 constexpr int kRefStack = 64;
 struct RefFrame {
