@@ -638,21 +638,23 @@ __device__ __forceinline__ PrimHit prim_intersect(const float4 *rec, v3 o, v3 d)
     return h;
 }
 
-// Folds the analytic primitives into a finished triangle walk: strict minimum, in list order.  Returns whether a
-// primitive came back at exactly the best distance (a tie the reference resolves by its own order).
+// Folds the analytic primitives into a finished triangle walk: strict minimum, in list order.  Returns whether
+// the reference's answer may depend on its own order here: a primitive came back at exactly the best distance,
+// or with a distance that is not below INF (a plane met at a grazing angle: the reference tests planes first, at
+// the root, with no distance cut, and keeps such a hit unless something nearer turns up, main.cpp:564-570).
 __device__ __forceinline__ bool analytic_closest(const DevScene &S, v3 o, v3 d, float &tBest, int &triBest) {
-    bool tie = false;
+    bool ask = false;
     for (uint32_t k = 0; k < S.nprims; ++k) {
         const PrimHit h = prim_intersect<false>(S.prims + 3 * (size_t)k, o, d);
         if (h.hit && h.t < tBest) {
             tBest = h.t;
             triBest = (int)(S.ntri + k);
-            tie = false;
-        } else if (h.hit && h.t == tBest) {
-            tie = true;
+            ask = false;
+        } else if (h.hit && (h.t == tBest || (triBest < 0 && !(h.t < kInf)))) {
+            ask = true;
         }
     }
-    return tie;
+    return ask;
 }
 
 // ---------------------------------------------------------------------------------------------
