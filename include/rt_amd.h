@@ -81,10 +81,11 @@ extern "C" {
  * its sequence of std::sort calls, leaves of four, pre-order numbering) next to its own and resolves these
  * cases as the reference does: the closest-hit calls and the RT_RNG_REFERENCE render walk the reference's
  * tree in the reference's order for EVERY ray (all of the above reproduced); the RT_RNG_COUNTER pipelines trace
- * on the library's own tree and hand the rays that met two primitives at the best distance, or an analytic
- * primitive at a distance not below INF (a plane at a grazing angle), to that walk (equal distances and such
- * plane hits reproduced; not the NaN and beyond-INF "hits" on triangles that only the reference's own walk
- * meets).  Available for scenes the reference itself can hold: at most 65535 primitives and
+ * on the library's own tree and hand to that walk the rays that met two primitives within 2e-5 of each other
+ * (coincident faces with different vertices land an ulp apart, and the reference's box arithmetic then decides),
+ * that met an analytic primitive at a distance not below INF (a plane at a grazing angle), or that start more
+ * than four scene sizes outside the scene (equal and nearly equal distances and such plane hits reproduced; not
+ * the NaN and beyond-INF "hits" on triangles that only the reference's own walk meets).  Available for scenes the reference itself can hold: at most 65535 primitives and
  * tree nodes (its ids are uint16_t, main.cpp:541-544), no unsplittable node of more than four primitives
  * (main.cpp:675-679 stores an out-of-range index there) and a tree of at most 64 levels; it is the default for
  * those (environment RT_HIT_ORDER=leaf at rt_scene_create overrides).

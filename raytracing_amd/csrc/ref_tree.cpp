@@ -66,9 +66,10 @@ inline uint32_t fbits(float f) {
 }
 
 // Ellipsoid / Box::calculateAABB (main.cpp:358-364, 457-463) through AABB::rotateAndTranslate (149-166)
-Bounds analytic_bounds(const rt_primitive &p) {
+// whole = true: the box the primitive really occupies (a Box intersects as +-param, main.cpp:370-373)
+Bounds analytic_bounds(const rt_primitive &p, bool whole = false) {
     float h[3];
-    for (int a = 0; a < 3; ++a) h[a] = p.type == RT_PRIM_BOX ? p.param[a] / 2.f : p.param[a];
+    for (int a = 0; a < 3; ++a) h[a] = (p.type == RT_PRIM_BOX && !whole) ? p.param[a] / 2.f : p.param[a];
     Bounds zero;
     zero.add(h);
     const float nh[3] = {-h[0], -h[1], -h[2]};
@@ -226,6 +227,27 @@ void build_ref_tree(const rt_scene_desc &desc, const std::vector<uint32_t> &reco
         q[13] = nd.right;
         q[14] = nd.first;
         q[15] = nd.count;
+    }
+    // what can really be hit below every node: children have larger numbers than their parent (pre-order)
+    out.reach.assign((size_t)out.nnodes * 8, 0.f);
+    {
+        std::vector<Bounds> reach(out.nnodes);
+        for (uint32_t k = out.nnodes; k-- > 0;) {
+            const Node &nd = nodes[k];
+            Bounds b;
+            for (uint32_t i = nd.first; i < nd.first + nd.count; ++i) {
+                const uint32_t p = order[i];
+                if (isPlane[p]) continue;  // only at the root, which nothing skips
+                b.add(p < ntri ? box[p] : analytic_bounds(desc.prims[p - ntri], true));
+            }
+            if (nd.left | nd.right) {
+                b.add(reach[nd.left]);
+                b.add(reach[nd.right]);
+            }
+            reach[k] = b;
+            float *q = &out.reach[(size_t)k * 8];
+            q[0] = b.lo[0], q[1] = b.lo[1], q[2] = b.lo[2], q[3] = b.hi[0], q[4] = b.hi[1], q[5] = b.hi[2];
+        }
     }
     out.items.resize(std::max<uint32_t>(total, 1u), 0u);
     for (uint32_t i = 0; i < total; ++i) {

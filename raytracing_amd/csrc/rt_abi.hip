@@ -322,6 +322,8 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
         RT_TRY(hipMemcpy(s->d_rnodes, f.ref.nodes.data(), f.ref.nodes.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         RT_TRY(dev_alloc(s, &s->d_ritems, f.ref.items.size()));
         RT_TRY(hipMemcpy(s->d_ritems, f.ref.items.data(), f.ref.items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        RT_TRY(dev_alloc(s, &s->d_rreach, f.ref.reach.size() / 4));
+        RT_TRY(hipMemcpy(s->d_rreach, f.ref.reach.data(), f.ref.reach.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     RT_TRY(dev_alloc(s, &s->d_counters, kCounterWords));
     RT_TRY(hipMemcpy(s->d_nodes, f.nodes.data(), f.nodes.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -355,6 +357,7 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
     v.prims = s->d_prims;
     v.rnodes = s->d_rnodes;
     v.ritems = s->d_ritems;
+    v.rreach = s->d_rreach;
     {
         // Results that depend on the reference's traversal order (equal distances above all: coincident faces, a
         // box standing on a floor) are resolved as the reference resolves them whenever the scene is one the
@@ -362,6 +365,10 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
         s->hit_order = f.ref.available ? RT_HITS_REFERENCE_ORDER : RT_HITS_LEAF_ORDER;
         if (const char *e = std::getenv("RT_HIT_ORDER"))
             if (std::strcmp(e, "leaf") == 0) s->hit_order = RT_HITS_LEAF_ORDER;
+        // tests: rt_intersect_rays in reference order answers with the pruned form of the reference's walk
+        // ("pruned"), or the way the throughput kernels do: fast walk, pruned walk where hits lay close ("ties")
+        if (const char *e = std::getenv("RT_TEST_INTERSECT_WALK"))
+            s->test_walk = std::strcmp(e, "pruned") == 0 ? 2 : std::strcmp(e, "ties") == 0 ? 3 : 0;
     }
     v.ntri = f.nslots;
     v.npad = f.nslots - f.ntri;
@@ -408,6 +415,18 @@ int scene_create_from_flat(std::shared_ptr<const FlatScene> flat, const rt_scene
     }
     // no walk visits a node or a leaf twice: nodes + leaves bounds the rounds and visits of one ray's walk (the wide
     // walk's retry included); four times that is the counting launches' alarm (TraceStats::runaway)
+    v.far_c[0] = v.far_c[1] = v.far_c[2] = 0.f;
+    v.far_r = 3.0e38f;
+    if (f.ref.available && f.ref.nnodes) {   // root of RefTree::reach: everything finite in the scene
+        const float *q = f.ref.reach.data();
+        float ext = 0.f;
+        for (int a = 0; a < 3; ++a) {
+            if (!(q[a] <= q[3 + a])) continue;   // nothing finite on this axis (a scene of planes)
+            v.far_c[a] = 0.5f * (q[a] + q[3 + a]);
+            ext = std::max(ext, q[3 + a] - q[a]);
+        }
+        if (ext > 0.f) v.far_r = 4.f * ext;
+    }
     v.step_bound = 4u * (f.nnodes + f.nslots + f.light_nnodes) + 64u;
     if (const char *e = std::getenv("RT_TEST_STEP_BOUND")) v.step_bound = (uint32_t)std::strtoul(e, nullptr, 10);  // tests: trip the alarm
     v.has_background = 0u;
@@ -439,6 +458,7 @@ void rt_scene_destroy(rt_scene *s) {
     (void)hipFree(s->d_prims);
     (void)hipFree(s->d_rnodes);
     (void)hipFree(s->d_ritems);
+    (void)hipFree(s->d_rreach);
     (void)hipFree(s->d_counters);
     delete s;
 }
@@ -492,7 +512,7 @@ int rt_intersect_rays_dev(rt_scene *s, uint64_t n, const float *d_origins, const
     if (n > (1ull << 31)) return fail(RT_ERR_LIMIT, "rt_intersect_rays_dev: more than 2^31 rays in one call");
     DeviceGuard g(s->device);
     RT_HIP(rt::launch_intersect(s->view, n, d_origins, d_directions, d_prim_id, d_t, s->counting,
-                                s->hit_order != RT_HITS_LEAF_ORDER, (hipStream_t)stream, s->timer));
+                                s->hit_order == RT_HITS_LEAF_ORDER ? 0 : (s->test_walk ? s->test_walk : 1), (hipStream_t)stream, s->timer));
     s->host_segments += n;
     return RT_OK;
 }

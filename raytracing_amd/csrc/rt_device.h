@@ -126,6 +126,7 @@ struct DevScene {
     const float4 *prims;      // 3 x float4 per analytic primitive: (position.xyz, bits(type)), rotation xyzw, (param.xyz, bits(material))
     const float4 *rnodes;     // 4 x float4 per node of the tree the reference itself would build (ref_closest_hit); null when the scene is beyond its limits
     const uint32_t *ritems;   // the reference's re-ordered primitive list as record indices (triangle record, or ntri + k)
+    const float4 *rreach;     // 2 x float4 per node of that tree: the box that holds everything a ray can hit below it
     unsigned long long *counters;  // kCounterShards x kCounterStride; per shard [0] segments [1] nodes [2] tri tests [3] light tests
     uint32_t nlights, nmats;             // nlights: all lights; the first ntrilights of them are triangles
     uint32_t ntrilights;
@@ -139,6 +140,10 @@ struct DevScene {
     float background[3];  // InputData::backgroundColor (main.cpp:694): radiance of a ray that hits nothing
     uint32_t has_background;  // any component nonzero
     float bin_scale[3];   // (position - grid_origin) * bin_scale = coordinate in units of one ray-sorting cell
+    // Reference order in the throughput kernels: a ray that starts farther than far_r from far_c (the middle of
+    // everything finite in the scene; far_r = four times its extent) is answered by the reference's walk: see
+    // far_origin().
+    float far_c[3], far_r;
     uint32_t step_bound;  // counting launches: no ray's walk can legitimately take more rounds / node visits than this
 };
 
@@ -172,6 +177,14 @@ struct TraceStats {
     // `cur` only while `leaf` holds another one -- and a state that breaks it would spin forever.
     uint32_t runaway;
 };
+
+// Value of lane `src` (0..63) of the wave: ds_bpermute with the byte address of that lane.  __shfl() adds the
+// caller's own lane number masked by the width to the index, which for the full width of 64 adds nothing and
+// keeps a register alive across the whole traversal loop.
+__device__ __forceinline__ int lane_value(int v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
+__device__ __forceinline__ float lane_value(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v)));
+}
 
 __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 #pragma unroll
@@ -230,6 +243,9 @@ __device__ __forceinline__ bool tri_test(float4 q0, float4 q1, float4 q2, v3 o, 
 // height bound (kStack inner levels) is what keeps the stack from overflowing.
 constexpr int kSentinel = 0x7FFFFFFF;  // "stack is empty": never a node index, never a leaf reference
 
+constexpr float kTieRelative = 2.0e-5f;  // see Traversal::consider
+constexpr float kTieAbsolute = 1.0e-7f;
+
 // TIES: the walk only notes (kTieBit of triBest) that a second primitive came back at exactly the best distance;
 // the caller then asks the reference's own walk, which answers in the reference's order.
 template <bool COUNT, int EXIT_LANES = 0, bool HELP = false, bool WIDE = false, bool TIES = false>
@@ -263,7 +279,9 @@ struct Traversal {
         if (__builtin_fabsf(v) < 1.0e-30f) v = __builtin_copysignf(1.0e-30f, v);
         return 1.f / v;
     }
-    __device__ __forceinline__ void start(const DevScene &S, v3 ro, v3 rd) { setup(S.grid_origin, S.grid_cell, ro, rd); }
+    __device__ __forceinline__ void start(const DevScene &S, v3 ro, v3 rd) {
+        setup(S.grid_origin, S.grid_cell, ro, rd);
+    }
     __device__ __forceinline__ void setup(const float *origin, const float *cell, v3 ro, v3 rd) {
         o = ro;
         d = rd;
@@ -309,14 +327,35 @@ struct Traversal {
     // triangle; with TIES the event is noted and the caller has the ray traced in the reference's order.
     // (The mark rides in a spare bit of triBest -- record indices stay below 2^26 -- so that a strictly nearer hit
     // clears it by being assigned, and the hot loop carries no extra register.)
+    // "Exactly the same distance" is too narrow a net.  Two coincident faces with different vertices get distances
+    // an ulp apart, and which of them the reference returns is then decided by the rounding of ITS box test: a flat
+    // node's slab is the plane itself, (plane - o) / d rounds differently from the triangle's 3x3 inverse, and
+    // `distance < minDistance` (main.cpp:587, 596) cuts the subtree that holds the hit an ulp nearer.  So the mark
+    // is set whenever two hits lie within tieTol of each other; the reference's own walk then answers, and for
+    // rays with one clear nearest hit it answers the same as this walk, only slower.
     static constexpr int kTieBit = 1 << 30;
+    // The tolerance: the reference's slab distance (plane - o) / d carries 2 ulp(coordinate) / (distance travelled
+    // along that axis), 1.2e-5 of t for a ray that crosses a hundredth of the scene on it.  Far wider nets catch
+    // honest geometry -- a lamp 2 mm under a ceiling -- and send a tenth of a Cornell box's rays the slow way
+    // (1e-3: the frame three times as slow) for answers the fast walk gets right.
+    // (Constants: a per-scene absolute term held in a register cost this kernel five spilled registers and 15 %.)
+    static constexpr float kTieRel = kTieRelative;
     __device__ __forceinline__ void consider(float t, int tri) {
-        if (t < tBest) {
+        if (TIES) {
+            // (nothing hit yet: tBest = INF is not within the tolerance of any hit that counts, and -1 | mark = -1)
+            const float gap = t - tBest;
+            const int mark = __builtin_fabsf(gap) <= __builtin_fmaf(kTieRel, t, kTieAbsolute) ? kTieBit : 0;
+            if (gap < 0.f) {
+                tBest = t;
+                triBest = tri | mark;
+            } else {
+                triBest |= mark;
+            }
+        } else if (t < tBest) {
             tBest = t;
             triBest = tri;
-        } else if (t == tBest) {
-            if (TIES) triBest |= kTieBit;
-            else if (tri < triBest) triBest = tri;
+        } else if (t == tBest && tri < triBest) {
+            triBest = tri;
         }
     }
     __device__ __forceinline__ bool tied() const { return TIES && triBest >= 0 && (triBest & kTieBit) != 0; }
@@ -501,11 +540,11 @@ struct Traversal {
             __builtin_amdgcn_wave_barrier();  // LDS serves a wave's operations in order; keep the compiler from moving them
             int src = (int)lane;
             if (help) src = (int)xchg[hrank];
-            const v3 ro = mk(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
-            const v3 rd = mk(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
+            const v3 ro = mk(lane_value(o.x, src), lane_value(o.y, src), lane_value(o.z, src));
+            const v3 rd = mk(lane_value(d.x, src), lane_value(d.y, src), lane_value(d.z, src));
             float t = kInf;
             bool hit = false;
-            const uint32_t firstOfSrc = (uint32_t)__shfl((int)first, src);  // every lane takes part in the shuffle
+            const uint32_t firstOfSrc = (uint32_t)lane_value((int)first, src);  // every lane takes part in the shuffle
             const uint32_t myTri = has ? first : firstOfSrc + 1u;
             if (has || help) {
                 const float4 *tp = S.tris + 4 * (size_t)myTri;
@@ -646,11 +685,12 @@ __device__ __forceinline__ bool analytic_closest(const DevScene &S, v3 o, v3 d, 
     bool ask = false;
     for (uint32_t k = 0; k < S.nprims; ++k) {
         const PrimHit h = prim_intersect<false>(S.prims + 3 * (size_t)k, o, d);
+        // (two hits within the tolerance of Traversal::consider: the reference's order decides)
         if (h.hit && h.t < tBest) {
+            ask = triBest >= 0 && tBest - h.t <= __builtin_fmaf(kTieRelative, tBest, kTieAbsolute);
             tBest = h.t;
             triBest = (int)(S.ntri + k);
-            ask = false;
-        } else if (h.hit && (h.t == tBest || (triBest < 0 && !(h.t < kInf)))) {
+        } else if (h.hit && (h.t - tBest <= __builtin_fmaf(kTieRelative, h.t, kTieAbsolute) || (triBest < 0 && !(h.t < kInf)))) {
             ask = true;
         }
     }
@@ -697,21 +737,29 @@ __device__ __forceinline__ float ref_box_distance(const float4 *n, v3 o, v3 d) {
 
 // tOut / recOut: distance and record index (triangle record, or S.ntri + k) of the reference's answer;
 // recOut < 0 and tOut = INF when it hits nothing.  tOut may be NaN or >= INF for a hit (see above).
-// PRUNE: a child whose TRUE box (minPoint / maxPoint, padded) the ray misses is not entered even where the
-// reference enters it (its slabs are twice the box).  No triangle in there can be hit, so the reference's call
-// returns "nothing" and changes neither its answer nor any later decision; skipping it keeps every answer that
-// is a matter of real hits -- equal distances above all -- and takes the walk from hundreds of node visits,
-// each a dependent trip to memory, to a few dozen (one ray of a 17 930-triangle scene: 1.1 ms -> under 0.1 ms; the
-// kernel that runs this finds a handful of rays per bounce and lasts as long as the slowest of them).  What it gives
-// up are the NaN "hits" of rays lying in a triangle's plane, which are not confined to any box: the validation
-// kernels walk with PRUNE = false.
-__device__ __forceinline__ bool ref_true_box_missed(const float4 *n, v3 o, v3 d) {
-    const float4 q1 = n[1], q2 = n[2];
-    const v3 lo = mk(q1.z, q1.w, q2.x), hi = mk(q2.y, q2.z, q2.w);
-    // padded far beyond the rounding of a hit point (1e-6 of its coordinates and of the distance travelled)
-    const v3 pad = mk(1.0e-3f + 1.0e-4f * __builtin_fmaxf(__builtin_fabsf(lo.x), __builtin_fabsf(hi.x)),
-                      1.0e-3f + 1.0e-4f * __builtin_fmaxf(__builtin_fabsf(lo.y), __builtin_fabsf(hi.y)),
-                      1.0e-3f + 1.0e-4f * __builtin_fmaxf(__builtin_fabsf(lo.z), __builtin_fabsf(hi.z)));
+// PRUNE: a child is not entered when the ray misses the box of everything that can be HIT below it (S.rreach: the
+// triangles' and primitives' real extents, padded), even where the reference enters it (its slabs are twice the
+// node's box).  Nothing in there can be hit, so the reference's call returns "nothing" and changes neither its
+// answer nor any later decision; skipping it keeps every answer that is a matter of real hits -- equal and nearly
+// equal distances above all -- and takes the walk from hundreds of node visits, each a dependent trip to memory,
+// to a few dozen (one ray of a 17 930-triangle scene: 1.1 ms -> under 0.1 ms; the kernel that runs this finds a
+// handful of rays per bounce and lasts as long as the slowest of them).  What it gives up are the NaN "hits" of
+// rays lying in a triangle's plane, which are not confined to any box: the validation kernels walk with
+// PRUNE = false.  (The node's own corner points will not do: the reference files an analytic Box under a box of
+// half its size.)
+__device__ __forceinline__ bool ref_reach_missed(const float4 *n, v3 o, v3 d) {
+    const float4 q0 = n[0], q1 = n[1];
+    const v3 lo = mk(q0.x, q0.y, q0.z), hi = mk(q0.w, q1.x, q1.y);
+    // Padded far beyond the rounding of a hit point (1e-6 of its coordinates and of the distance travelled), and
+    // in proportion to the distance of the origin as well: what the reference's own arithmetic reports as hit
+    // blurs with it.  Its ellipsoid test squares (o - centre) / radius and subtracts 1 (main.cpp:290-296); from
+    // 4000 units away (a ray coming back from a plane it met out there) that difference is noise, and a ray
+    // passing 1.4 units beside a sphere of radius 0.15 "hits" it: |o| * 2^-11.5.  The reference reports such hits
+    // wherever its doubled slabs let the walk reach the primitive, so the pruned walk must not skip them either.
+    const float far = 1.0e-3f * __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z));
+    const v3 pad = mk(far + 1.0e-3f + 1.0e-3f * __builtin_fmaxf(__builtin_fabsf(lo.x), __builtin_fabsf(hi.x)),
+                      far + 1.0e-3f + 1.0e-3f * __builtin_fmaxf(__builtin_fabsf(lo.y), __builtin_fabsf(hi.y)),
+                      far + 1.0e-3f + 1.0e-3f * __builtin_fmaxf(__builtin_fabsf(lo.z), __builtin_fabsf(hi.z)));
     const v3 a = vdiv((lo - pad) - o, d), b = vdiv((hi + pad) - o, d);
     const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a.x, b.x), __builtin_fminf(a.y, b.y)), __builtin_fminf(a.z, b.z));
     const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a.x, b.x), __builtin_fmaxf(a.y, b.y)), __builtin_fmaxf(a.z, b.z));
@@ -764,8 +812,8 @@ __device__ __forceinline__ void ref_walk(const DevScene &S, v3 o, v3 d, RefFrame
                 ld -= rd;
             }
             if (PRUNE) {  // as if the reference had walked the child and found nothing
-                if (ref_true_box_missed(S.rnodes + 4 * (size_t)left, o, d)) ld = kBigInf;
-                if (ref_true_box_missed(S.rnodes + 4 * (size_t)right, o, d)) rd = kBigInf;
+                if (ref_reach_missed(S.rreach + 2 * (size_t)left, o, d)) ld = kBigInf;
+                if (ref_reach_missed(S.rreach + 2 * (size_t)right, o, d)) rd = kBigInf;
             }
             if (sp < depth) {
                 if (ld < ct) {  // minDistance = closestIntersection.t, main.cpp:571
@@ -813,6 +861,16 @@ __device__ __noinline__ void ref_closest_hit(const DevScene &S, v3 o, v3 d, floa
     ref_walk<COUNT, PRUNE>(S, o, d, fr, 1, kRefStack, tOut, recOut, st);
 }
 
+// Reference order in the throughput kernels: a ray that starts far outside the scene -- it comes back from an
+// analytic plane it met hundreds of scene sizes away -- is answered by the reference's walk, not by the fast one.
+// Out there the reference's own intersection arithmetic is noise (its ellipsoid test "hits" a sphere of radius
+// 0.15 from 1.4 units beside it at 4000 units distance, see ref_reach_missed), and WHICH of those phantom hits
+// the reference reports is decided by where its doubled slabs let its walk go: only that walk knows.
+__device__ __forceinline__ bool far_origin(const DevScene &S, v3 o) {
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x - S.far_c[0]), __builtin_fabsf(o.y - S.far_c[1])),
+                           __builtin_fabsf(o.z - S.far_c[2])) > S.far_r;
+}
+
 // How a kernel answers where the reference's result depends on its traversal order:
 //   kOrderLeaf       own tree, equal distances go to the triangle earlier in leaf order
 //   kOrderRefTies    own tree; a ray that met two primitives at the best distance is traced again by ref_closest_hit
@@ -838,7 +896,7 @@ __device__ __forceinline__ void closest_hit(const DevScene &S, v3 o, v3 d, int *
     triBest = T.best();
     bool tie = T.tied();
     if (S.nprims) tie = analytic_closest(S, o, d, tBest, triBest) || tie;
-    if (ORDER == kOrderRefTies && tie) ref_closest_hit<COUNT, true>(S, o, d, tBest, triBest, st);
+    if (ORDER == kOrderRefTies && (tie || far_origin(S, o))) ref_closest_hit<COUNT, true>(S, o, d, tBest, triBest, st);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -82,6 +82,10 @@ struct RefTree {
     bool available = false;
     std::string reason;            // why not, when not available
     std::vector<uint32_t> nodes;   // nnodes * 16
+    // nnodes * 8: (lo.xyz, hi.x), (hi.yz, -, -): a box that really holds everything a ray can hit below the node.
+    // Not the node's own box: the reference gives an analytic Box a tree box of HALF its size (main.cpp:457-463,
+    // made whole again by the doubled slabs), so a walk that skips what a ray cannot hit must not trust it.
+    std::vector<float> reach;
     std::vector<uint32_t> items;   // primitive list in the reference's order, as record indices
     std::vector<uint32_t> order;   // the same list as loader ids (triangle id, or ntri + k)
     uint32_t nnodes = 0;

@@ -65,8 +65,11 @@ __device__ __forceinline__ uint32_t tri_loader_id(const DevScene &S, int tri) {
     return __float_as_uint(S.tris[4 * (size_t)tri + 3].x);
 }
 
-// REF: every ray is answered by the reference's own walk over the reference's own tree (ref_closest_hit).
-template <bool COUNT, bool REF>
+// REF 1: every ray is answered by the reference's own walk over the reference's own tree (ref_closest_hit);
+// REF 2 (tests): by that walk in the pruned form the throughput kernels use for the rays they hand over;
+// REF 3 (tests): as the megakernel answers in reference order -- the fast walk, and that pruned walk for the rays
+// on which two hits lay close together.
+template <bool COUNT, int REF>
 __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, uint64_t n, const float *__restrict__ o,
                                                        const float *__restrict__ d, uint32_t *__restrict__ prim_id,
                                                        float *__restrict__ tout) {
@@ -78,7 +81,9 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, uint64_t n, co
     float t;
     int tri;
     TraceStats st{0, 0, 0, 0, 0};
-    closest_hit<COUNT, REF ? kOrderRefFull : kOrderLeaf>(S, ro, rd, s_stack + threadIdx.x, t, tri, st);
+    if (REF == 2) ref_closest_hit<COUNT, true>(S, ro, rd, t, tri, st);
+    else if (REF == 3) closest_hit<COUNT, kOrderRefTies>(S, ro, rd, s_stack + threadIdx.x, t, tri, st);
+    else closest_hit<COUNT, REF ? kOrderRefFull : kOrderLeaf>(S, ro, rd, s_stack + threadIdx.x, t, tri, st);
     prim_id[i] = tri >= 0 ? tri_loader_id(S, tri) : 0xFFFFFFFFu;
     tout[i] = t;
     if (COUNT) add_counters(S, 0u, st, 0u, true);  // the host adds one segment per ray
@@ -381,7 +386,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? kWideWaves : 1) void wf_extend(DevSc
                 bool tie = T.tied();
                 T.triBest = T.best();
                 if (PRIMS) tie = (analytic_closest(S, T.o, T.d, T.tBest, T.triBest) || tie) && TIES;
-                again = tie;
+                again = tie || (TIES && far_origin(S, T.o));
             }
             if (again) {
                 const uint32_t at = atomicAdd(retry_count, 1u);  // (slot, where its hit goes)
@@ -833,12 +838,14 @@ namespace rt {
 static uint32_t *tune_bounce_host(uint32_t *tune, uint32_t b) { return tune + 8u + 4u * (b < kTuneBounces ? b : kTuneBounces - 1u); }
 
 hipError_t launch_intersect(const DevScene &S, uint64_t n, const float *o, const float *d, uint32_t *prim_id, float *t,
-                            bool count, bool ref_order, hipStream_t stream, KernelTimer &timer) {
+                            bool count, int ref_order, hipStream_t stream, KernelTimer &timer) {
     if (n == 0) return hipSuccess;
     const uint32_t grid = (uint32_t)((n + kBlock - 1) / kBlock);
     timer.begin(kKernClosestHit, stream);
-    auto kern = ref_order ? (count ? k_intersect<true, true> : k_intersect<false, true>)
-                          : (count ? k_intersect<true, false> : k_intersect<false, false>);
+    auto kern = ref_order == 3 ? (count ? k_intersect<true, 3> : k_intersect<false, 3>)
+                : ref_order == 2 ? (count ? k_intersect<true, 2> : k_intersect<false, 2>)
+                : ref_order    ? (count ? k_intersect<true, 1> : k_intersect<false, 1>)
+                               : (count ? k_intersect<true, 0> : k_intersect<false, 0>);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, stream, S, n, o, d, prim_id, t);
     timer.end(stream);
     return hipGetLastError();

@@ -115,7 +115,7 @@ struct WavefrontBuffers {
 };
 
 hipError_t launch_intersect(const rtd::DevScene &S, uint64_t n, const float *o, const float *d, uint32_t *prim_id,
-                            float *t, bool count, bool ref_order, hipStream_t stream, KernelTimer &timer);
+                            float *t, bool count, int ref_order, hipStream_t stream, KernelTimer &timer);
 hipError_t launch_primary(const rtd::DevScene &S, uint32_t W, uint32_t H, uint32_t *prim_id, float *t, bool count,
                           bool ref_order, hipStream_t stream, KernelTimer &timer);
 // ref_order (only for scenes that hold the reference's tree, S.rnodes): results that depend on the reference's

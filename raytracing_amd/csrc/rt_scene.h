@@ -20,7 +20,9 @@ struct rt_scene {
     float4 *d_prims = nullptr;  // analytic primitives, 3 x float4 each
     float4 *d_rnodes = nullptr;   // the reference's own tree (FlatScene::ref), when the scene is within its limits
     uint32_t *d_ritems = nullptr;
+    float4 *d_rreach = nullptr;   // RefTree::reach
     int hit_order = RT_HITS_LEAF_ORDER;  // RT_HITS_*: how order-dependent hits are resolved (rt_scene_set_hit_order)
+    int test_walk = 0;  // RT_TEST_INTERSECT_WALK (tests): 2 pruned, 3 ties
     unsigned long long *d_counters = nullptr;
     rt::WavefrontBuffers wf;
     uint32_t *d_replay = nullptr;  // vertex records of the replay kernel, grown to the largest request

@@ -570,6 +570,51 @@ def test_reference_tree_equals_the_oracles_build(scene_dir, oracle_mod, name, kw
         assert set(ref["order"][:2]) == {ntri + 1, ntri + 5} and nodes[0, 2] == 0 and nodes[0, 3] >= 2
 
 
+def test_reference_tree_on_random_soups(oracle_mod):
+    """The same comparison on 60 random soups built to stress the ORDER of the build: many equal centroid
+    coordinates (triangles on a lattice, duplicated triangles), so that what std::sort does with equal keys --
+    it is not stable, and the reference sorts four times per node -- decides which primitive lands in which
+    leaf.  Where the oracle's build meets a node that no split improves, the product must report that there is no
+    reference tree instead of building one."""
+    import raytracing_amd as rt
+    mats = np.zeros(1, dtype=rt.api.MATERIAL_DTYPE)
+    mats["color"] = 0.5
+    cam = dict(position=[0, 0, 3], right=[1, 0, 0], up=[0, 1, 0], forward=[0, 0, -1], tan_x=0.5, tan_y=0.5)
+    built = refused = 0
+    for seed in range(60):
+        rng = np.random.RandomState(1000 + seed)
+        n = int(rng.choice([5, 9, 33, 200, 1000, 3000]))
+        kind = seed % 4
+        if kind == 0:      # a lattice: centroids share coordinates on every axis
+            c = rng.randint(0, 6, size=(n, 1, 3)).astype(np.float32) * 0.25
+            tri = c + np.array([[0, 0, 0], [0.2, 0, 0], [0, 0.2, 0]], np.float32)[None] * rng.choice([1.0, -1.0], size=(n, 1, 1))
+        elif kind == 1:    # random, with a tenth of the triangles duplicated
+            tri = rng.uniform(-1, 1, size=(n, 1, 3)) + rng.uniform(-0.1, 0.1, size=(n, 3, 3))
+            k = max(n // 10, 1)
+            tri[:k] = tri[k:2 * k]
+        elif kind == 2:    # a flat sheet (one axis degenerate) of mixed sizes
+            tri = rng.uniform(-1, 1, size=(n, 1, 3)) + rng.uniform(-0.5, 0.5, size=(n, 3, 3)) * 10.0 ** rng.uniform(-3, 0, size=(n, 1, 1))
+            tri[:, :, 1] = 0.25
+        else:              # clusters far apart
+            tri = rng.choice([-50.0, 0.0, 70.0], size=(n, 1, 3)) + rng.uniform(-0.3, 0.3, size=(n, 3, 3))
+        tri = np.ascontiguousarray(tri, dtype=np.float32)
+        host = rt.HostScene(tri, np.zeros(n, np.uint32), mats, cam)
+        orc = oracle_mod.OracleScene(tri, np.zeros(n, np.uint32), mats, cam)
+        ref = rt.build_flat(host)["ref_tree"]
+        if orc.info()["unsplittable"]:
+            assert ref is None, "seed %d: a reference tree although the reference's build breaks on this scene" % seed
+            refused += 1
+        else:
+            assert ref is not None, "seed %d" % seed
+            nodes, boxes, items = orc.tree()
+            assert np.array_equal(ref["nodes"][:, 12:], nodes), "seed %d: topology" % seed
+            assert np.array_equal(ref["nodes"][:, :12], boxes.view(np.uint32)), "seed %d: boxes" % seed
+            assert np.array_equal(ref["order"], items), "seed %d: primitive order" % seed
+            built += 1
+        orc.close()
+    assert built >= 30 and refused >= 1, (built, refused)
+
+
 def test_reference_tree_limits():
     """Beyond what the reference can hold (uint16_t ids, main.cpp:541-544) or build (a node of more than four
     primitives that no split improves, main.cpp:675-679) there is no reference tree: the build says why and the
