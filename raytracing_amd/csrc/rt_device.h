@@ -344,7 +344,8 @@ struct Traversal {
         if (TIES) {
             // (nothing hit yet: tBest = INF is not within the tolerance of any hit that counts, and -1 | mark = -1)
             const float gap = t - tBest;
-            const int mark = __builtin_fabsf(gap) <= __builtin_fmaf(kTieRel, t, kTieAbsolute) ? kTieBit : 0;
+            // (written as "not clearly apart" so that a NaN distance -- a ray in the triangle's plane -- marks too)
+            const int mark = __builtin_fabsf(gap) > __builtin_fmaf(kTieRel, t, kTieAbsolute) ? 0 : kTieBit;
             if (gap < 0.f) {
                 tBest = t;
                 triBest = tri | mark;
