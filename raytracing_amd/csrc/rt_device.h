@@ -242,6 +242,7 @@ __device__ __forceinline__ bool tri_test(float4 q0, float4 q1, float4 q2, v3 o, 
 // A pending entry exists only for an inner node on the current root-to-leaf path, so the builder's
 // height bound (kStack inner levels) is what keeps the stack from overflowing.
 constexpr int kSentinel = 0x7FFFFFFF;  // "stack is empty": never a node index, never a leaf reference
+constexpr uint32_t kHelperMiss = 0xFFFFFFFFu;  // a helper lane's "no hit" (a NaN with every payload bit set)
 
 constexpr float kTieRelative = 2.0e-5f;  // see Traversal::consider
 constexpr float kTieAbsolute = 1.0e-7f;
@@ -551,7 +552,9 @@ struct Traversal {
                 const float4 *tp = S.tris + 4 * (size_t)myTri;
                 hit = tri_test(tp[0], tp[1], tp[2], ro, rd, t);
             }
-            if (help) xchg[64 + hrank] = __float_as_uint(hit ? t : kInf);
+            // (a miss travels as a bit pattern no arithmetic produces, so that whatever the test returned -- a NaN
+            // distance included -- reaches consider() exactly as it does when the owner runs the test itself)
+            if (help) xchg[64 + hrank] = hit ? __float_as_uint(t) : kHelperMiss;
             __builtin_amdgcn_wave_barrier();
             if (COUNT) {  // passes of the wave through the triangle test: one, two if a second triangle found no helper
                 const uint32_t passes = (has ? 1u : 0u) + ((cnt == 2u && !lend) ? 1u : 0u);
@@ -561,8 +564,8 @@ struct Traversal {
                 if (COUNT) st.tris += cnt;
                 if (hit) consider(t, (int)first);
                 if (lend) {
-                    const float t2 = __uint_as_float(xchg[64 + drank]);  // kInf when the helper's test missed
-                    if (t2 < kInf) consider(t2, (int)first + 1);
+                    const uint32_t b2 = xchg[64 + drank];
+                    if (b2 != kHelperMiss) consider(__uint_as_float(b2), (int)first + 1);
                 } else if (cnt == 2u) {  // more two-triangle leaves than idle lanes: test it here
                     const float4 *tp = S.tris + 4 * (size_t)(first + 1u);
                     float t2;

@@ -116,8 +116,11 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, uint32_t W, uint
 // ALIGHT: the light list holds emissive analytic primitives; their sampling and density code sits in functions
 // that are not inlined, and a kernel that may call one pays for the callee's registers and a call stack whether
 // a scene has such lights or not (146 instead of 82 VGPRs here, 3 instead of 5 waves per SIMD, -34 % rays/s).
+// kOrderRefTies at four waves per SIMD: the call to the reference-order walker for the few rays that need it
+// makes the compiler budget 144 registers (three waves); held to 128 it spills 19 of them and the Cornell box
+// renders at 9.95 instead of 8.67 Grays/s (leaf order, which has no such call: 10.86; five waves, 52 spills: 8.88).
 template <bool COUNT, bool TREE, int ORDER, bool ALIGHT>
-__global__ __launch_bounds__(kBlock) void k_render_mega(DevScene S, rt::RenderParams rp, float *__restrict__ sum) {
+__global__ __launch_bounds__(kBlock, ORDER == kOrderRefTies ? 4 : 1) void k_render_mega(DevScene S, rt::RenderParams rp, float *__restrict__ sum) {
     __shared__ int s_stack[kStack * kBlock];
     __shared__ LightCacheStorage s_lights;
     const LightCache LC = load_light_cache(S, s_lights, s_stack + threadIdx.x);
