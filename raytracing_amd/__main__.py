@@ -6,7 +6,8 @@ samples split over all ranks when launched under torch.distributed.run (one proc
     python -m torch.distributed.run --nproc-per-node 8 -m raytracing_amd scene.gltf 1920 1080 1024 out.ppm
 
 Options: --depth N (default 6), --rng reference|counter (default reference on one GPU; several
-GPUs need counter), --pipeline mega|wavefront, --seed S.
+GPUs need counter), --pipeline mega|wavefront, --seed S, --hit-order leaf|reference|walk (how hits that depend
+on the reference's traversal order are resolved; default: reference where the scene is one the reference can hold).
 """
 import argparse
 import os
@@ -25,6 +26,7 @@ def main(argv=None):
     ap.add_argument("--rng", choices=["reference", "counter"], default=None)
     ap.add_argument("--pipeline", choices=["mega", "wavefront"], default=None)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--hit-order", choices=["leaf", "reference", "walk"], default=None)
     a = ap.parse_args(argv)
     start = time.perf_counter()
 
@@ -47,6 +49,9 @@ def main(argv=None):
         dist.init_process_group(backend="nccl", device_id=dev)
 
     scene = rt.Scene(rt.load_gltf(a.scene, a.width, a.height), device=local_rank)
+    if a.hit_order:
+        scene.set_hit_order({"leaf": rt.HITS_LEAF_ORDER, "reference": rt.HITS_REFERENCE_ORDER,
+                             "walk": rt.HITS_REFERENCE_WALK}[a.hit_order])
     if rank == 0:
         print("Processed input after %gs" % (time.perf_counter() - start))
     npix = a.width * a.height
