@@ -89,9 +89,9 @@ extern "C" {
  * tree nodes (its ids are uint16_t, main.cpp:541-544), no unsplittable node of more than four primitives
  * (main.cpp:675-679 stores an out-of-range index there) and a tree of at most 64 levels; it is the default for
  * those (environment RT_HIT_ORDER=leaf at rt_scene_create overrides).
- * RT_HITS_REFERENCE_WALK: as RT_HITS_REFERENCE_ORDER, and the RT_RNG_COUNTER megakernel too sends every ray through
- * the reference's walk (slow; a validation aid: its ray-segment counts then equal the CPU path's even where a path
- * meets a NaN hit).  The wavefront pipeline behaves as under RT_HITS_REFERENCE_ORDER.
+ * RT_HITS_REFERENCE_WALK: as RT_HITS_REFERENCE_ORDER, and the RT_RNG_COUNTER pipelines too send every ray through
+ * the reference's walk (slow; a validation aid: their ray-segment counts then equal the CPU path's even where a
+ * path meets a NaN hit).
  * RT_HITS_LEAF_ORDER: the library's own tree only; of two primitives at exactly the same distance the one
  * earlier in the library's leaf order wins; NaN distances and t >= INF are misses.  The only mode for larger
  * scenes. */

@@ -608,6 +608,7 @@ int rt_render_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp_beg
         rc = ensure_wavefront(s, width * height, slots);
         if (rc != RT_OK) return rc;
         s->wf.ties = ref_order;
+        s->wf.ref_all = s->hit_order == RT_HITS_REFERENCE_WALK;
         RT_HIP(rt::launch_render_wavefront(s->view, rp, d_radiance_sum, s->wf, slots, s->counting, (hipStream_t)stream, s->timer));
     }
     return RT_OK;
@@ -649,6 +650,7 @@ int rt_render_noalloc_dev(rt_scene *s, uint32_t width, uint32_t height, uint32_t
     wb.sort_min_rays = s->sort_min_rays;
     wb.wide = s->wide_tree;
     wb.ties = s->hit_order != RT_HITS_LEAF_ORDER;
+    wb.ref_all = s->hit_order == RT_HITS_REFERENCE_WALK;
     wb.ref_depth = s->flat->ref.depth;
     wb.ref_frames = reinterpret_cast<rtd::RefFrame *>(base + kScratchRefFrames);
     wb.ref_lanes = (uint32_t)(kNoAllocRefFrames / (wb.ref_depth + 1) / rtd::kBlock) * rtd::kBlock;   // at least 64 blocks: depth <= 64

@@ -504,6 +504,23 @@ __global__ __launch_bounds__(kBlock) void wf_extend_retry(DevScene S, WfView V, 
     }
 }
 
+// RT_HITS_REFERENCE_WALK: no fast walk at all.  Stands in for wf_extend: every ray of the bounce's queue goes onto
+// the list wf_extend_retry_ref works off, and the queue the next shading pass fills starts empty.  A validation
+// mode (one lane walks each ray through the reference's tree of double-size boxes): never sorted, never timed.
+__global__ __launch_bounds__(kBlock) void wf_list_all(const uint32_t *__restrict__ queue, const uint32_t *__restrict__ qcount_in,
+                                                       uint32_t *__restrict__ qcount_zero, uint32_t *__restrict__ retry,
+                                                       uint32_t *__restrict__ retry_count) {
+    const uint32_t count = *qcount_in;
+    for (uint32_t q = blockIdx.x * kBlock + threadIdx.x; q < count; q += gridDim.x * kBlock) {
+        retry[2 * (size_t)q] = queue ? queue[q] : q;  // the path's slot
+        retry[2 * (size_t)q + 1] = q;                 // its hit goes to the queue position
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *retry_count = count;
+        *qcount_zero = 0u;
+    }
+}
+
 // The same list in scenes whose hits are resolved in the reference's order: every ray of it (the rays that met two
 // primitives at the best distance, and those the wide walk ran out of stack on) by the reference's own walk.  The
 // walk's frames lie in global memory, `frames[level * lanes + lane]` (coalesced), lanes = threads of the launch.
@@ -512,7 +529,8 @@ __global__ __launch_bounds__(kBlock) void wf_extend_retry(DevScene S, WfView V, 
 // visit two or three dependent trips to memory.  Hence the pruned walk (ref_walk<PRUNE>): 17 930 triangles, 33 M
 // paths per bounce: 1.1 ms per launch unpruned, 0.3 to 0.8 pruned (4.6 % of that frame; 0.4 % of the Cornell frame).
 constexpr uint32_t kRefRetryBlocks = 256;  // x 256 lanes, each with (tree depth + 1) frames of 16 bytes
-template <bool COUNT>
+// PRUNE = false: the reference's walk as it is, for RT_HITS_REFERENCE_WALK, where wf_list_all hands over every ray.
+template <bool COUNT, bool PRUNE>
 __global__ __launch_bounds__(kBlock) void wf_extend_retry_ref(DevScene S, WfView V, const uint32_t *__restrict__ retry,
                                                                const uint32_t *__restrict__ retry_count, uint32_t camera_rays,
                                                                RefFrame *__restrict__ frames, int depth) {
@@ -531,7 +549,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_retry_ref(DevScene S, WfView
         }
         float t;
         int tri;
-        ref_walk<COUNT, true>(S, o, d, frames + me, (int)lanes, depth, t, tri, st);
+        ref_walk<COUNT, PRUNE>(S, o, d, frames + me, (int)lanes, depth, t, tri, st);
         V.hit[hitAt] = make_float2(t, __int_as_float(tri));
         ++segs;
     }
@@ -939,7 +957,7 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
             const uint32_t *qshade = (qu < 0) ? nullptr : wb.queue[qu];
             const int fill = (qu == 0) ? 1 : 0;
             // may the queue this bounce fills be regrouped?  (the tuner keeps books for kTuneBounces bounces)
-            const bool sort = wb.sort && b >= kSortFromBounce && b + 1 < bounces && (wb.sort == 1 || b + 1 < kTuneBounces);
+            const bool sort = wb.sort && !wb.ref_all && b >= kSortFromBounce && b + 1 < bounces && (wb.sort == 1 || b + 1 < kTuneBounces);
             const SortChoice next{sort ? (uint32_t)wb.sort : 0u, tune_bounce_host(wb.tuner, b + 1) + 2};
             timer.begin(kKernExtend, stream);
             uint32_t *retry = wb.retry, *retryCount = wb.qcount + 2;
@@ -949,13 +967,19 @@ hipError_t launch_render_wavefront(const DevScene &S, const RenderParams &rp, fl
             auto ext = wb.wide ? (wb.ties ? RT_EXT(true, true) : RT_EXT(true, false))
                                : (wb.ties ? RT_EXT(false, true) : RT_EXT(false, false));
 #undef RT_EXT
-            hipLaunchKernelGGL(ext, dim3(egrid), dim3(kBlock), 0, stream, S, V, qshade, qsorted, traced, wb.qcount + in,
-                               wb.qcount + out, wb.cursors, retry, retryCount, wb.stack_limit, tune, b, wb.sort_min_rays);
+            if (wb.ref_all)
+                hipLaunchKernelGGL(wf_list_all, dim3(grid), dim3(kBlock), 0, stream, qshade, wb.qcount + in, wb.qcount + out, retry,
+                                   retryCount);
+            else
+                hipLaunchKernelGGL(ext, dim3(egrid), dim3(kBlock), 0, stream, S, V, qshade, qsorted, traced, wb.qcount + in,
+                                   wb.qcount + out, wb.cursors, retry, retryCount, wb.stack_limit, tune, b, wb.sort_min_rays);
             if (wb.ties) {
                 const int depth = (int)wb.ref_depth + 1;
                 const uint32_t rblocks = wb.ref_lanes / kBlock;   // the host sized the frame buffer for this many lanes
-                hipLaunchKernelGGL(count ? wf_extend_retry_ref<true> : wf_extend_retry_ref<false>, dim3(rblocks), dim3(kBlock), 0, stream,
-                                   S, V, retry, retryCount, b == 0 ? 1u : 0u, wb.ref_frames, depth);
+                auto rref = wb.ref_all ? (count ? wf_extend_retry_ref<true, false> : wf_extend_retry_ref<false, false>)
+                                       : (count ? wf_extend_retry_ref<true, true> : wf_extend_retry_ref<false, true>);
+                hipLaunchKernelGGL(rref, dim3(rblocks), dim3(kBlock), 0, stream, S, V, retry, retryCount, b == 0 ? 1u : 0u,
+                                   wb.ref_frames, depth);
             } else if (wb.wide) {
                 hipLaunchKernelGGL(count ? wf_extend_retry<true> : wf_extend_retry<false>, dim3(kRetryGrid), dim3(kBlock), 0, stream, S, V,
                                    retry, retryCount, b == 0 ? 1u : 0u);

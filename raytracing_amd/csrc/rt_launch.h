@@ -106,6 +106,7 @@ struct WavefrontBuffers {
     uint32_t *tuner = nullptr;  // kWfTuneWords words, zero when allocated and then the tuner's own (mode 2)
     bool wide = true;         // wf_extend walks the four-child tree
     bool ties = false;        // rays that met two primitives at the best distance are traced again in the reference's order
+    bool ref_all = false;     // ... and so is every other ray, by the unpruned walk (RT_HITS_REFERENCE_WALK; implies ties)
     uint32_t ref_depth = 0;   // ... by a walk over the reference's own tree: its deepest level,
     rtd::RefFrame *ref_frames = nullptr;  // (ref_depth + 1) x ref_lanes frames of that walk,
     uint32_t ref_lanes = 0;   // and the lanes (a multiple of 256) the frames are laid out for

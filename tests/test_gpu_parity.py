@@ -550,6 +550,11 @@ def test_ray_sorting_tuner_on_paths_deeper_than_its_books(scene_dir, oracle_mod,
         gpu.reset_counters()
         _assert_close(gpu.render(W, H, 6, max_depth=depth, rng_mode=1, seed=4, pipeline=rt.PIPE_MEGAKERNEL), ref)
         assert gpu.counters()["segments"] == c_o["segments"]
+        # ... and so does the wavefront pipeline, whose trace kernel then only lists the rays for the reference's walk
+        gpu.reset_counters()
+        _assert_close(gpu.render(W, H, 6, max_depth=depth, rng_mode=1, seed=4, pipeline=rt.PIPE_WAVEFRONT), ref)
+        c = gpu.counters()
+        assert c["segments"] == c_o["segments"] == c["retraced"]
 
 
 @pytest.mark.parametrize("name,kw,W,H,depth", [
