@@ -1008,6 +1008,28 @@ def test_command_line_end_to_end(scene_dir, oracle_mod, tmp_path):
         os.remove(out)
 
 
+@pytest.mark.parametrize("name", ["cornell", "cornell_onfloor"])
+def test_config1_the_reference_cpu_case_at_its_own_size(scene_dir, oracle_mod, name):
+    """BASELINE config 1: the reference's plumbing case, a Cornell-box glTF at 640x480 with 16 samples and the
+    reference's fixed depth of 6 (main.cpp:1216), its own random stream.  Radiance sums bit for bit, image floats
+    and bytes equal, ray-segment count equal -- also with the boxes standing ON the floor (coincident faces)."""
+    import raytracing_amd as rt
+    W, H, spp = 640, 480, 16
+    host, gpu, orc = _load(scene_dir, oracle_mod, name, W, H)
+    ref, c_o = orc.render(W, H, spp, max_depth=6, rng_mode=0)
+    gpu.reset_counters()
+    out = gpu.render(W, H, spp, max_depth=6, rng_mode=rt.RNG_REFERENCE)
+    _assert_bits_equal_nan(out, ref)
+    assert gpu.counters()["segments"] == c_o["segments"]
+    img_o, rgb_o = oracle_mod.tonemap(ref, spp)
+    img_g, rgb_g = gpu.tonemap(out, spp)
+    assert np.array_equal(rgb_g, rgb_o)
+    same = (img_g.view(np.uint32) == img_o.view(np.uint32)) | (np.isnan(img_g) & np.isnan(img_o))
+    assert same.all()
+    gpu.close()
+    orc.close()
+
+
 @pytest.mark.parametrize("name,kw,W,H,spp,depth", [
     ("emissive", {"subdiv": 2, "lamps": 3}, 96, 72, 2, 5),     # 960 light triangles
     ("cornell", {}, 96, 72, 4, 6),                              # 2 lights, tree forced
