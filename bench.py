@@ -226,6 +226,12 @@ def main():
         if "l1_accesses" in rec:
             out["vmem"] = {"achieved": round(rec["l1_accesses"] * scale / seconds / 1e9, 1), "peak": round(256 * 2.4, 1),
                            "unit": "G L1 accesses/s", "peak_source": "theoretical: 256 CUs x 2.4 GHz x one 64-byte L1 access per cycle"}
+        if "l1_accesses" in rec and "gui_active_cycles_sum_xcd" in rec and rec.get("duration_ms"):
+            # per cycle the chip actually ran (GRBM_GUI_ACTIVE of the same launches: the clock under this kernel is
+            # below the 2.4 GHz of the peak), next to what the gather microbenchmark sustains per cycle
+            cyc = rec["gui_active_cycles_sum_xcd"] / 8.0
+            out["vmem"]["clock_GHz_in_the_pmc_launches"] = round(cyc / (rec["duration_ms"] * 1e-3) / 1e9, 3)
+            out["vmem"]["accesses_per_cycle_and_cu"] = round(rec["l1_accesses"] / (256.0 * cyc), 3)
         if "valu_wave_insts" in rec and "gui_active_cycles_sum_xcd" in rec:
             cycles = rec["gui_active_cycles_sum_xcd"] / 8.0     # the counter sums the 8 XCDs
             out["valu"] = {"achieved": round(rec["valu_wave_insts"] * 2.0 / cycles, 1), "peak": 256 * 4.0,
@@ -233,6 +239,7 @@ def main():
         for v in out.values():
             v["frac"] = round(v["achieved"] / v["peak"], 4)
         return out
+
 
     kernels, traffic, pmc_src, gather = {}, None, None, None
     rpath = os.path.join(ROOT, "profiles", "pmc_rates.json")
